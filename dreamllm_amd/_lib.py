@@ -1,0 +1,89 @@
+"""ctypes loader for the C-ABI HIP library (`include/dreamllm_hip.h`).
+
+The library is the product's only compute path: if it is missing, `lib()` raises -- there is no CPU / eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdreamllm_hip.so")
+
+c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+DLLM_BF16, DLLM_F32 = 0, 1
+
+_ERRORS = {-1: "bad shape", -2: "unsupported dtype", -3: "kernel launch failed", -4: "misaligned pointer/stride"}
+
+# name -> argtypes (return type is always int)
+SIGNATURES = {
+    "dllm_norm_bwd_nparts": [c_i64],
+    "dllm_rmsnorm_fwd": [c_void_p] * 6 + [c_i64, c_int, c_float, c_void_p],
+    "dllm_rmsnorm_bwd": [c_void_p] * 8 + [c_int, c_i64, c_int, c_void_p],
+    "dllm_layernorm_fwd": [c_void_p] * 6 + [c_i64, c_int, c_float, c_void_p],
+    "dllm_layernorm_bwd": [c_void_p] * 10 + [c_int, c_i64, c_int, c_void_p],
+    "dllm_gemm_bf16": [c_void_p] * 5 + [c_i64] * 7 + [c_int] * 5 + [c_float, c_void_p],
+    "dllm_conv2d_nhwc_bf16": [c_void_p] * 5 + [c_int] * 15 + [c_void_p],
+    "dllm_attn_fwd": [c_void_p] * 6 + [c_int] * 6 + [c_i64] * 9 + [c_float, c_int, c_void_p],
+    "dllm_attn_bwd": [c_void_p] * 11 + [c_int] * 6 + [c_i64] * 9 + [c_float, c_int, c_void_p],
+    "dllm_rope": [c_void_p] * 4 + [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void_p],
+    "dllm_glu_fwd": [c_void_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_i64, c_int, c_void_p],
+    "dllm_glu_bwd": [c_void_p] * 5 + [c_i64, c_int] + [c_i64] * 5 + [c_int, c_void_p],
+    "dllm_gather_rows": [c_void_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_void_p],
+    "dllm_scatter_rows": [c_void_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_void_p],
+    "dllm_segment_sum_rows": [c_void_p] * 5 + [c_i64, c_int, c_i64, c_i64, c_void_p],
+    "dllm_cross_entropy": [c_void_p] * 5 + [c_i64, c_int, c_i64, c_i64, c_void_p],
+    "dllm_adamw": [c_void_p] * 4 + [c_i64, c_int, c_int] + [c_float] * 5 + [c_int, c_float, c_void_p],
+    "dllm_sumsq": [c_void_p, c_i64, c_int, c_void_p, c_void_p],
+    "dllm_mse_sum": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p],
+    "dllm_mse_bwd": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
+    "dllm_probe_tr16": [c_void_p, c_void_p, c_void_p],
+    "dllm_probe_mfma16": [c_void_p, c_void_p, c_void_p, c_void_p],
+}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -m dreamllm_amd.build` (hipcc, gfx950). "
+                "dreamllm_amd has no CPU fallback."
+            )
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            try:
+                fn = getattr(_lib, name)
+            except AttributeError:
+                continue  # reported by tests/test_abi.py; calling it raises below
+            fn.argtypes = argtypes
+            fn.restype = c_int
+    return _lib
+
+
+def call(name: str, *args) -> int:
+    fn = getattr(lib(), name, None)
+    if fn is None:
+        raise HipLibraryMissing(f"symbol {name} missing from {LIB_PATH}")
+    rc = fn(*args)
+    return rc
+
+
+def check(name: str, *args) -> None:
+    """Call and turn negative error codes into the exceptions the reference would raise (ValueError for shapes)."""
+    rc = call(name, *args)
+    if rc == 0:
+        return
+    msg = f"{name} failed: {_ERRORS.get(rc, rc)}"
+    if rc in (-1, -4):
+        raise ValueError(msg)
+    if rc == -2:
+        raise TypeError(msg)
+    raise RuntimeError(msg)

@@ -1,0 +1,119 @@
+// Shared pieces of the flash-attention kernels (forward, dQ, dK/dV): LDS images of [rows][D] bf16 tiles,
+// fragment reads, and global -> register -> LDS staging.
+//
+// All three kernels work in the "transposed" formulation: S^T = K Q^T, O^T = V^T P^T, so a lane owns one query
+// (column lane&15) and softmax statistics never leave the lane's 16-lane column group.  A [rows][D] tile is kept
+// in LDS once, in its natural row-major image, and read two ways:
+//   * row-fragments  (16 rows x 32 d, d contiguous)      -> ds_read_b128 from an XOR-swizzled image  (QK^T / dO V^T)
+//   * col-fragments  (16 d   x 32 rows, rows = MFMA k)   -> ds_read_b64_tr_b16 transpose reads       (PV / dS K ...)
+// Two images are therefore defined: ROW image (b128-friendly swizzle) and COL image (tr-read-friendly swizzle).
+#pragma once
+#include "common.h"
+
+template <int D>
+struct TileImg {
+    static constexpr int PITCH = D * 2;    // bytes per row
+    static constexpr int CPR = D / 8;      // 16-byte chunks per row
+    // ROW image: chunk c of row r lives at chunk position c ^ sw(r); 16 rows x same chunk -> 16 distinct 16-B slots.
+    __device__ static __forceinline__ int row_off(int r, int c) {
+        if constexpr (D == 128)
+            return r * PITCH + ((c ^ (r & 15)) << 4);
+        else
+            return r * PITCH + ((c ^ ((r >> 1) & 7)) << 4);
+    }
+    // COL image: 32-byte slot s of row r lives at slot s ^ sw(r); the 8 consecutive rows a half-wave touches in one
+    // transpose read land on distinct bank groups.
+    __device__ static __forceinline__ int col_off(int r, int byte_in_row) {
+        const int s = byte_in_row >> 5;
+        int sw;
+        if constexpr (D == 128)
+            sw = r & 7;
+        else
+            sw = (r >> 1) & 3;
+        return r * PITCH + ((s ^ sw) << 5) + (byte_in_row & 31);
+    }
+    // row-fragment: lane gets row (rbase + lane&15), d = dstep*32 + (lane>>4)*8 .. +7
+    __device__ static __forceinline__ bf16x8 frag_row(const char* tile, int rbase, int dstep, int lane) {
+        return *reinterpret_cast<const bf16x8*>(tile + row_off(rbase + (lane & 15), dstep * 4 + (lane >> 4)));
+    }
+    // col-fragment over two groups of 4 rows: lane (g = lane>>4, t = lane&15) gets column d = dbase + t and
+    // rows {r_lo + g*4 + 0..3} then {r_hi + g*4 + 0..3} as the 8 MFMA k-slots of its group.
+    __device__ static __forceinline__ bf16x8 frag_col(const char* tile, int dbase, int r_lo, int r_hi, int lane) {
+        const int g = lane >> 4, t = lane & 15;
+        const int bcol = dbase * 2 + (t & 3) * 8;
+        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + col_off(r_lo + g * 4 + (t >> 2), bcol)));
+        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + col_off(r_hi + g * 4 + (t >> 2), bcol)));
+        union {
+            struct { short4v a, b; } s;
+            bf16x8 v;
+        } u;
+        u.s.a = lo;
+        u.s.b = hi;
+        return u.v;
+    }
+    // col-fragment read out of a ROW image (tile that is also read with frag_row): 2-way bank conflict, no second copy.
+    __device__ static __forceinline__ bf16x8 frag_col_rowimg(const char* tile, int dbase, int r_lo, int r_hi, int lane) {
+        const int g = lane >> 4, t = lane & 15;
+        const int bcol = dbase * 2 + (t & 3) * 8;
+        const int c = bcol >> 4, w = bcol & 15;
+        short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + row_off(r_lo + g * 4 + (t >> 2), c) + w));
+        short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + row_off(r_hi + g * 4 + (t >> 2), c) + w));
+        union {
+            struct { short4v a, b; } s;
+            bf16x8 v;
+        } u;
+        u.s.a = lo;
+        u.s.b = hi;
+        return u.v;
+    }
+};
+
+// Staging of a [ROWS][D] tile by NT threads: chunk index i = tid + NT*p -> row i / CPR, chunk i % CPR.
+template <int D, int ROWS, int NT>
+struct TileStage {
+    static constexpr int CPR = D / 8;
+    static constexpr int NP = (ROWS * CPR) / NT;
+    bf16x8 v[NP];
+    __device__ __forceinline__ void gload(const bf16* base, int64_t row_stride, int row0, int nrows_valid, int tid) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = tid + NT * p;
+            const int r = i / CPR, c = i % CPR;
+            if (row0 + r < nrows_valid)
+                v[p] = ld_bf16x8(base + (int64_t)(row0 + r) * row_stride + c * 8);
+            else
+                v[p] = zero_bf16x8();
+        }
+    }
+    __device__ __forceinline__ void lstore_row(char* tile, int tid) const {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = tid + NT * p;
+            *reinterpret_cast<bf16x8*>(tile + TileImg<D>::row_off(i / CPR, i % CPR)) = v[p];
+        }
+    }
+    __device__ __forceinline__ void lstore_col(char* tile, int tid) const {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int i = tid + NT * p;
+            *reinterpret_cast<bf16x8*>(tile + TileImg<D>::col_off(i / CPR, (i % CPR) * 16)) = v[p];
+        }
+    }
+};
+
+struct AttnParams {
+    const bf16* q; const bf16* k; const bf16* v; bf16* o;
+    const bf16* dout; bf16* dq; bf16* dk; bf16* dv;
+    float* lse;          // [B, H, Sq]
+    float* delta;        // [B, H, Sq]  rowsum(dO * O)
+    const int* seqlens;  // [B] valid length (self-attention with right padding) or null
+    int B, H, Hkv, Sq, Sk;
+    int64_t q_sb, q_ss, q_sh;      // element strides of q / o / dout / dq
+    int64_t k_sb, k_ss, k_sh;      // element strides of k / v / dk / dv
+    int64_t o_sb, o_ss, o_sh;
+    float scale;
+    int causal;
+};
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;

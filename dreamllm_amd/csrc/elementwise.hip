@@ -1,0 +1,432 @@
+// HBM-bound elementwise / gather / loss / optimizer kernels of the DreamLLM hot path (gfx950).
+// All use 16-byte (8 x bf16) accesses, fp32 math, one rounding on store.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ RoPE (modeling_dreamllm.py:176-209)
+// x: [T tokens][NH heads][D] view (token stride ts, head stride hs, d contiguous), rotated in place:
+//   y1 = x1*cos - x2*sin ; y2 = x2*cos + x1*sin   with (x1, x2) the two halves of the head dim ("rotate_half").
+// cs: fp32 [max_pos][D/2] cos table, sn likewise; pos: int64 [T] position ids or null (=> token index % S).
+// sign = -1 gives the backward (transpose rotation).
+__global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ x, const float* __restrict__ cs,
+                                                   const float* __restrict__ sn, const int64_t* __restrict__ pos, int64_t T,
+                                                   int S, int NH, int D, int64_t ts, int64_t hs, float sign) {
+    const int half = D >> 1, vph = half >> 3;  // 8-element vectors per half
+    const int64_t total = T * NH * vph;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int j = (int)(i % vph);
+        const int64_t th = i / vph;
+        const int hh = (int)(th % NH);
+        const int64_t tok = th / NH;
+        const int64_t p = pos ? pos[tok] : (tok % S);
+        bf16* p1 = x + tok * ts + (int64_t)hh * hs + j * 8;
+        bf16* p2 = p1 + half;
+        const bf16x8 a = ld_bf16x8(p1), b = ld_bf16x8(p2);
+        const float* c = cs + p * half + j * 8;
+        const float* s = sn + p * half + j * 8;
+        bf16x8 o1, o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float cc = c[e], ss = s[e] * sign;
+            const float x1 = (float)a[e], x2 = (float)b[e];
+            o1[e] = (bf16)(x1 * cc - x2 * ss);
+            o2[e] = (bf16)(x2 * cc + x1 * ss);
+        }
+        st_bf16x8(p1, o1);
+        st_bf16x8(p2, o2);
+    }
+}
+
+// ------------------------------------------------------------------ SwiGLU / GEGLU
+// MODE 0: out = silu(a) * b   (DreamLLMMLP, modeling_dreamllm.py:237)     a = gate, b = up
+// MODE 1: out = b_ * gelu(a)  with a = gate half, b = value half (diffusers GEGLU: hidden, gate = chunk(2); hidden*gelu(gate))
+template <int MODE>
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
+                                                      bf16* __restrict__ out, int64_t M, int F, int64_t lda, int64_t ldb,
+                                                      int64_t ldo) {
+    const int vpr = F >> 3;
+    const int64_t total = M * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i % vpr) * 8;
+        const bf16x8 av = ld_bf16x8(a + r * lda + c), bv = ld_bf16x8(b + r * ldb + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = (float)av[e], y = (float)bv[e];
+            o[e] = (bf16)((MODE == 0 ? silu_f(x) : gelu_erf_f(x)) * y);
+        }
+        st_bf16x8(out + r * ldo + c, o);
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ a,
+                                                      const bf16* __restrict__ b, bf16* __restrict__ da, bf16* __restrict__ db,
+                                                      int64_t M, int F, int64_t ldd, int64_t lda, int64_t ldb, int64_t ldda,
+                                                      int64_t lddb) {
+    const int vpr = F >> 3;
+    const int64_t total = M * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i % vpr) * 8;
+        const bf16x8 dv = ld_bf16x8(dout + r * ldd + c), av = ld_bf16x8(a + r * lda + c), bv = ld_bf16x8(b + r * ldb + c);
+        bf16x8 oa, ob;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float d = (float)dv[e], x = (float)av[e], y = (float)bv[e];
+            float act, dact;
+            if (MODE == 0) {
+                const float sg = sigmoid_f(x);
+                act = x * sg;
+                dact = sg * (1.f + x * (1.f - sg));
+            } else {
+                act = gelu_erf_f(x);
+                dact = gelu_erf_grad_f(x);
+            }
+            oa[e] = (bf16)(d * y * dact);
+            ob[e] = (bf16)(d * act);
+        }
+        st_bf16x8(da + r * ldda + c, oa);
+        st_bf16x8(db + r * lddb + c, ob);
+    }
+}
+
+// ------------------------------------------------------------------ row gather / scatter (embedding + multimodal splice)
+// out[i,:] = table[idx[i],:]
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16* __restrict__ table, const int64_t* __restrict__ idx,
+                                                          bf16* __restrict__ out, int64_t n, int D, int64_t ld_t,
+                                                          int64_t ld_o) {
+    const int vpr = D >> 3;
+    const int64_t total = n * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i % vpr) * 8;
+        st_bf16x8(out + r * ld_o + c, ld_bf16x8(table + idx[r] * ld_t + c));
+    }
+}
+// dst[idx[i],:] = src[i,:]   (idx unique)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16* __restrict__ src, const int64_t* __restrict__ idx,
+                                                           bf16* __restrict__ dst, int64_t n, int D, int64_t ld_s,
+                                                           int64_t ld_d) {
+    const int vpr = D >> 3;
+    const int64_t total = n * vpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / vpr;
+        const int c = (int)(i % vpr) * 8;
+        st_bf16x8(dst + idx[r] * ld_d + c, ld_bf16x8(src + r * ld_s + c));
+    }
+}
+// Embedding backward, deterministic: rows sorted by token id; seg_start[u]..seg_start[u+1] are the positions (into
+// `order`) of unique id uid[u].  dtable[uid[u],:] = sum_{j in segment} dy[order[j],:]  (fp32 accumulation).
+__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const bf16* __restrict__ dy, const int64_t* __restrict__ order,
+                                                               const int64_t* __restrict__ seg_start,
+                                                               const int64_t* __restrict__ uid, bf16* __restrict__ dtable,
+                                                               int64_t nuniq, int D, int64_t ld_dy, int64_t ld_t) {
+    const int vpr = D >> 3;
+    for (int64_t u = blockIdx.x; u < nuniq; u += gridDim.x) {
+        const int64_t s0 = seg_start[u], s1 = seg_start[u + 1];
+        for (int v = threadIdx.x; v < vpr; v += 256) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int64_t j = s0; j < s1; ++j) {
+                const bf16x8 d = ld_bf16x8(dy + order[j] * ld_dy + v * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)d[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+            st_bf16x8(dtable + uid[u] * ld_t + v * 8, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ softmax cross-entropy over fp32 logits
+// (modeling_dreamllm.py:1453-1470: logits.float(), CrossEntropyLoss(reduction="none"), mean over labels != -100).
+// One block per row.  loss_row[r] = lse - logit[label] (0 for ignored rows);  dlogits (bf16, optional) =
+// (softmax - onehot) * gscale for valid rows, 0 for ignored rows, where gscale = dloss / n_valid is read from a
+// device scalar so no host sync is needed.
+__global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                         float* __restrict__ loss_row, bf16* __restrict__ dlogits,
+                                                         const float* __restrict__ gscale_ptr, int V, int64_t ld_l,
+                                                         int64_t ld_d) {
+    __shared__ float scratch[4];
+    const int64_t r = blockIdx.x;
+    const float* row = logits + r * ld_l;
+    const int64_t label = labels[r];
+    const bool valid = label >= 0 && label < V;
+    if (!valid && dlogits == nullptr) {
+        if (threadIdx.x == 0) loss_row[r] = 0.f;
+        return;
+    }
+    float mx = -INFINITY;
+    if (valid || true) {
+        for (int c = threadIdx.x * 4; c < V; c += 1024) {
+            if (c + 3 < V) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+                mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+            } else {
+                for (int e = c; e < V; ++e) mx = fmaxf(mx, row[e]);
+            }
+        }
+    }
+    mx = block_max<4>(mx, scratch);
+    float se = 0.f;
+    for (int c = threadIdx.x * 4; c < V; c += 1024) {
+        if (c + 3 < V) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            se += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx);
+        } else {
+            for (int e = c; e < V; ++e) se += __expf(row[e] - mx);
+        }
+    }
+    se = block_sum<4>(se, scratch);
+    const float lse = mx + logf(se);
+    if (threadIdx.x == 0) loss_row[r] = valid ? (lse - row[label]) : 0.f;
+    if (dlogits != nullptr) {
+        const float gs = valid ? gscale_ptr[0] : 0.f;
+        bf16* drow = dlogits + r * ld_d;
+        for (int c = threadIdx.x * 4; c < V; c += 1024) {
+            if (c + 3 < V) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float p = __expf(v[e] - lse);
+                    if (c + e == label) p -= 1.f;
+                    o[e] = (bf16)(p * gs);
+                }
+                st_bf16x4(drow + c, o);
+            } else {
+                for (int e = c; e < V; ++e) {
+                    float p = __expf(row[e] - lse);
+                    if (e == label) p -= 1.f;
+                    drow[e] = (bf16)(p * gs);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ AdamW (decoupled weight decay), fp32 math
+// p, g: bf16 or fp32 by flag; m, v: same dtype as given by state_f32.  Matches torch.optim.AdamW(fused) update:
+//   p *= 1 - lr*wd ; m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+template <typename PT, typename ST>
+__global__ __launch_bounds__(256) void adamw_kernel(PT* __restrict__ p, const PT* __restrict__ g, ST* __restrict__ m,
+                                                    ST* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float pf = (float)p[i];
+        const float gf = (float)g[i] * gscale;
+        float mf = (float)m[i], vf = (float)v[i];
+        pf *= 1.f - lr * wd;
+        mf = b1 * mf + (1.f - b1) * gf;
+        vf = b2 * vf + (1.f - b2) * gf * gf;
+        const float denom = sqrtf(vf) / sqrtf(bc2) + eps;
+        pf -= (lr / bc1) * mf / denom;
+        p[i] = (PT)pf;
+        m[i] = (ST)mf;
+        v[i] = (ST)vf;
+    }
+}
+
+// sum of squares of a bf16/fp32 buffer into a fp32 accumulator (grad-norm clipping); atomicAdd of per-block partials.
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float scratch[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = (float)x[i];
+        s += v * v;
+    }
+    s = block_sum<4>(s, scratch);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+// mean((a - b)^2) partial sums: out += sum (a-b)^2 ; dgrad (optional): da = 2 (a - b) * gscale[0] / n
+__global__ __launch_bounds__(256) void mse_kernel(const bf16* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                  float* __restrict__ out) {
+    __shared__ float scratch[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = (float)a[i] - b[i];
+        s += d * d;
+    }
+    s = block_sum<4>(s, scratch);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+__global__ __launch_bounds__(256) void mse_bwd_kernel(const bf16* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                      const float* __restrict__ gscale, bf16* __restrict__ da) {
+    const float gs = 2.f * gscale[0] / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        da[i] = (bf16)(((float)a[i] - b[i]) * gs);
+}
+
+// ------------------------------------------------------------------ transpose-read semantics probe (test infrastructure)
+__global__ void probe_tr16_kernel(const short* __restrict__ in, short* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) short lds[64 * 4];
+    for (int i = threadIdx.x; i < 256; i += 64) lds[i] = in[i];
+    __syncthreads();
+    short4v r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, lds + threadIdx.x * 4));
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = r[j];
+}
+__global__ void probe_mfma_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, float* __restrict__ out) {
+    // a: [16][32] row-major (row, k); b: [16][32] (col, k).  lane supplies row/col lane&15, k = (lane>>4)*8..
+    const int lane = threadIdx.x;
+    bf16x8 fa = ld_bf16x8(a + (lane & 15) * 32 + (lane >> 4) * 8);
+    bf16x8 fb = ld_bf16x8(b + (lane & 15) * 32 + (lane >> 4) * 8);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) out[lane * 4 + r] = acc[r];
+}
+
+inline int grid_for(int64_t total, int per_block = 256) {
+    int64_t b = (total + per_block - 1) / per_block;
+    if (b > 8192) b = 8192;  // 256 CUs x 8 blocks x 4: grid-stride the rest
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dllm_rope(void* x, const float* cos_tab, const float* sin_tab, const int64_t* pos, int64_t T, int S, int NH, int D,
+              int64_t tok_stride, int64_t head_stride, int backward, void* stream) {
+    if (T < 0 || NH <= 0 || (D % 16) != 0 || S <= 0) return DLLM_ERR_SHAPE;
+    if ((tok_stride | head_stride) & 7) return DLLM_ERR_ALIGN;
+    if (T == 0) return DLLM_OK;
+    const int64_t total = T * NH * (D / 16);
+    hipLaunchKernelGGL(rope_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (bf16*)x, cos_tab, sin_tab, pos,
+                       T, S, NH, D, tok_stride, head_stride, backward ? -1.0f : 1.0f);
+    return dllm_check_launch();
+}
+
+// mode 0: SwiGLU out = silu(a)*b ; mode 1: GEGLU out = gelu(a)*b
+int dllm_glu_fwd(const void* a, const void* b, void* out, int64_t M, int F, int64_t lda, int64_t ldb, int64_t ldo, int mode,
+                 void* stream) {
+    if (M < 0 || F <= 0 || (F & 7) || ((lda | ldb | ldo) & 7)) return DLLM_ERR_SHAPE;
+    if (M == 0) return DLLM_OK;
+    const int g = grid_for(M * (F / 8));
+    if (mode == 0)
+        hipLaunchKernelGGL(glu_fwd_kernel<0>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b,
+                           (bf16*)out, M, F, lda, ldb, ldo);
+    else
+        hipLaunchKernelGGL(glu_fwd_kernel<1>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b,
+                           (bf16*)out, M, F, lda, ldb, ldo);
+    return dllm_check_launch();
+}
+int dllm_glu_bwd(const void* dout, const void* a, const void* b, void* da, void* db, int64_t M, int F, int64_t ldd, int64_t lda,
+                 int64_t ldb, int64_t ldda, int64_t lddb, int mode, void* stream) {
+    if (M < 0 || F <= 0 || (F & 7) || ((ldd | lda | ldb | ldda | lddb) & 7)) return DLLM_ERR_SHAPE;
+    if (M == 0) return DLLM_OK;
+    const int g = grid_for(M * (F / 8));
+    if (mode == 0)
+        hipLaunchKernelGGL(glu_bwd_kernel<0>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, (const bf16*)a,
+                           (const bf16*)b, (bf16*)da, (bf16*)db, M, F, ldd, lda, ldb, ldda, lddb);
+    else
+        hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, (const bf16*)a,
+                           (const bf16*)b, (bf16*)da, (bf16*)db, M, F, ldd, lda, ldb, ldda, lddb);
+    return dllm_check_launch();
+}
+
+int dllm_gather_rows(const void* table, const int64_t* idx, void* out, int64_t n, int D, int64_t ld_t, int64_t ld_o,
+                     void* stream) {
+    if (n < 0 || D <= 0 || (D & 7) || ((ld_t | ld_o) & 7)) return DLLM_ERR_SHAPE;
+    if (n == 0) return DLLM_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n * (D / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)table,
+                       idx, (bf16*)out, n, D, ld_t, ld_o);
+    return dllm_check_launch();
+}
+int dllm_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int D, int64_t ld_s, int64_t ld_d,
+                      void* stream) {
+    if (n < 0 || D <= 0 || (D & 7) || ((ld_s | ld_d) & 7)) return DLLM_ERR_SHAPE;
+    if (n == 0) return DLLM_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(n * (D / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)src,
+                       idx, (bf16*)dst, n, D, ld_s, ld_d);
+    return dllm_check_launch();
+}
+int dllm_segment_sum_rows(const void* dy, const int64_t* order, const int64_t* seg_start, const int64_t* uid, void* dtable,
+                          int64_t nuniq, int D, int64_t ld_dy, int64_t ld_t, void* stream) {
+    if (nuniq < 0 || D <= 0 || (D & 7) || ((ld_dy | ld_t) & 7)) return DLLM_ERR_SHAPE;
+    if (nuniq == 0) return DLLM_OK;
+    const int g = (int)(nuniq < 4096 ? nuniq : 4096);
+    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, order, seg_start,
+                       uid, (bf16*)dtable, nuniq, D, ld_dy, ld_t);
+    return dllm_check_launch();
+}
+
+int dllm_cross_entropy(const float* logits, const int64_t* labels, float* loss_row, void* dlogits, const float* gscale,
+                       int64_t rows, int V, int64_t ld_logits, int64_t ld_dlogits, void* stream) {
+    if (rows < 0 || V <= 0 || (ld_logits & 3)) return DLLM_ERR_SHAPE;
+    if (dlogits != nullptr && ((ld_dlogits & 3) || gscale == nullptr)) return DLLM_ERR_SHAPE;
+    if (rows == 0) return DLLM_OK;
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, logits, labels, loss_row,
+                       (bf16*)dlogits, gscale, V, ld_logits, ld_dlogits);
+    return dllm_check_launch();
+}
+
+int dllm_adamw(void* p, const void* g, void* m, void* v, int64_t n, int param_dtype, int state_dtype, float lr, float beta1,
+               float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    if (n < 0 || step < 1) return DLLM_ERR_SHAPE;
+    if (n == 0) return DLLM_OK;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    const int gsz = grid_for(n);
+    hipStream_t s = (hipStream_t)stream;
+    if (param_dtype == DLLM_BF16 && state_dtype == DLLM_BF16)
+        hipLaunchKernelGGL((adamw_kernel<bf16, bf16>), dim3(gsz), dim3(256), 0, s, (bf16*)p, (const bf16*)g, (bf16*)m, (bf16*)v,
+                           n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    else if (param_dtype == DLLM_BF16 && state_dtype == DLLM_F32)
+        hipLaunchKernelGGL((adamw_kernel<bf16, float>), dim3(gsz), dim3(256), 0, s, (bf16*)p, (const bf16*)g, (float*)m,
+                           (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    else if (param_dtype == DLLM_F32 && state_dtype == DLLM_F32)
+        hipLaunchKernelGGL((adamw_kernel<float, float>), dim3(gsz), dim3(256), 0, s, (float*)p, (const float*)g, (float*)m,
+                           (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+    else
+        return DLLM_ERR_DTYPE;
+    return dllm_check_launch();
+}
+
+// out (fp32 scalar, must be zeroed by the caller) += sum x^2
+int dllm_sumsq(const void* x, int64_t n, int dtype, float* out, void* stream) {
+    if (n < 0) return DLLM_ERR_SHAPE;
+    if (n == 0) return DLLM_OK;
+    int g = grid_for(n);
+    if (g > 1024) g = 1024;
+    if (dtype == DLLM_BF16)
+        hipLaunchKernelGGL(sumsq_kernel<bf16>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, n, out);
+    else if (dtype == DLLM_F32)
+        hipLaunchKernelGGL(sumsq_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, n, out);
+    else
+        return DLLM_ERR_DTYPE;
+    return dllm_check_launch();
+}
+
+// out (zeroed fp32 scalar) += sum (pred - target)^2 ; pred bf16, target fp32
+int dllm_mse_sum(const void* pred, const float* target, int64_t n, float* out, void* stream) {
+    if (n < 0) return DLLM_ERR_SHAPE;
+    if (n == 0) return DLLM_OK;
+    int g = grid_for(n);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(mse_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)pred, target, n, out);
+    return dllm_check_launch();
+}
+int dllm_mse_bwd(const void* pred, const float* target, int64_t n, const float* gscale, void* dpred, void* stream) {
+    if (n < 0) return DLLM_ERR_SHAPE;
+    if (n == 0) return DLLM_OK;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16*)pred, target, n,
+                       gscale, (bf16*)dpred);
+    return dllm_check_launch();
+}
+
+// test-only probes of the gfx950 fragment conventions the kernels rely on
+int dllm_probe_tr16(const void* in256, void* out256, void* stream) {
+    hipLaunchKernelGGL(probe_tr16_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const short*)in256, (short*)out256);
+    return dllm_check_launch();
+}
+int dllm_probe_mfma16(const void* a, const void* b, float* out256, void* stream) {
+    hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, out256);
+    return dllm_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,421 @@
+// bf16 MFMA GEMM family for gfx950 (fp32 accumulate) with fused epilogues, plus NHWC implicit-GEMM convolution.
+//
+//   C[M,N] = epilogue( A[M,K] * B[K,N] )
+//
+// One kernel template covers every contraction on the DreamLLM hot path:
+//   forward  linear  y = x W^T      : A k-contiguous ([M,K]),  B k-contiguous (weight [N,K])      -> (A_K, B_K)
+//   dgrad            dx = dy W      : A k-contiguous ([M,N']), B n-contiguous (weight as [K',N])  -> (A_K, B_N)
+//   wgrad            dW = dy^T x    : A m-contiguous (dy as [K',M]), B n-contiguous (x as [K',N]) -> (A_M, B_N)
+//   conv3x3 / 1x1 on NHWC           : A gathered per (row, tap) with zero padding                 -> (A_CONV, B_K)
+// Reference call sites replaced: nn.Linear in DreamLLMAttention/DreamLLMMLP/lm_head
+// (omni/models/dreamllm/modeling_dreamllm.py:219-237,273-276,1216), the projectors
+// (omni/models/projector/mlp_projector.py:19,39-44) and the linears/convs inside CLIPVisionModel and
+// UNet2DConditionModel ([ext]).
+//
+// Structure: 128x128x64 block tile, 256 threads = 4 waves (2x2), wave tile 64x64 = 4x4 MFMA 16x16x32 tiles.
+// Operands are staged global -> registers -> LDS (double buffered, one barrier per K tile, the next tile's global
+// loads are in flight during the MFMAs).  k-contiguous tiles are read with ds_read_b128 from an XOR-swizzled
+// [rows][64] image; reduction-dim-strided tiles keep their natural [64][128] image and are read with the gfx950
+// transpose read ds_read_b64_tr_b16, so no operand is ever transposed in HBM.  The MFMA is issued with the operands
+// swapped (D^T = B^T A^T) so every lane ends up with 4 consecutive output columns of one row -> 8/16-byte stores.
+// blockIdx is remapped so each XCD (private 4 MiB L2) works on a contiguous group of tiles (GROUP_M swizzle).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int A_K = 0, A_M = 1, A_CONV = 2;
+constexpr int B_K = 0, B_N = 1;
+
+constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
+
+struct ConvGeom {
+    int H, W, C;     // physical input spatial dims and channels (NHWC)
+    int OH, OW;      // output spatial dims
+    int KH, KW;      // 3x3 or 1x1
+    int stride;      // 1 or 2 (forward)
+    int pad;         // 1 for 3x3, 0 for 1x1
+    int up_shift;    // 1: logical input is the nearest-2x upsampled image (physical = logical >> 1)
+    int even_only;   // 1: transposed (dgrad of a stride-2 conv): logical index must be even, physical = logical >> 1
+};
+
+struct GemmParams {
+    const bf16* A;
+    const bf16* B;
+    void* C;
+    const bf16* bias;      // [N] or null
+    const bf16* residual;  // [M, ldr] or null (added after activation)
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc, ldr;
+    int epi;
+    int out_f32;     // C dtype
+    int accumulate;  // C += result
+    float alpha;     // scale applied to the accumulator before bias
+    ConvGeom cv;
+};
+
+// ---- LDS images -------------------------------------------------------------------------------------------------
+// k-contiguous tile: [128 rows][64 k] bf16, 128 B per row, 16-B chunk c stored at chunk c ^ ((row >> 1) & 7):
+// conflict-free for ds_read_b128 fragment reads (16 distinct rows, same chunk) and for the staging ds_write_b128.
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// m-contiguous tile: [64 k rows][128 m] bf16, 256 B per row, 32-B slot s stored at s ^ f(krow),
+// f = (krow & 3) | ((krow >> 3) & 1) << 2: the 8 k rows one half-wave touches in a transpose read hit 8 distinct slots.
+__device__ __forceinline__ int mc_off(int krow, int byte_in_row) {
+    const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+    return krow * 256 + ((((byte_in_row >> 5) ^ f)) << 5) + (byte_in_row & 31);
+}
+
+__device__ __forceinline__ bf16x8 frag_kc(const char* tile, int row, int kk, int lane) {
+    return *reinterpret_cast<const bf16x8*>(tile + kc_off(row, kk * 4 + (lane >> 4)));
+}
+
+__device__ __forceinline__ bf16x8 frag_mc(const char* tile, int mbase, int kk, int lane) {
+    // lane (g = lane>>4, t = lane&15) receives m = mbase + t, k = kk*32 + g*8 + 0..7
+    const int g = lane >> 4, t = lane & 15;
+    const int k0 = kk * 32 + g * 8 + (t >> 2);
+    const int bcol = mbase * 2 + (t & 3) * 8;
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + mc_off(k0, bcol)));
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + mc_off(k0 + 4, bcol)));
+    union {
+        struct { short4v a, b; } s;
+        bf16x8 v;
+    } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+}
+
+// ---- global -> register staging -----------------------------------------------------------------------------------
+struct Stage {
+    bf16x8 v[4];
+};
+
+// k-contiguous operand: thread t loads rows (t>>3) + 32p, chunk t&7.
+__device__ __forceinline__ void gload_kc(Stage& s, const bf16* base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
+                                         int64_t K, int tid) {
+    const int chunk = tid & 7;
+    const int64_t k = k0 + chunk * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t row = row0 + (tid >> 3) + 32 * p;
+        if (row < nrows && k < K)
+            s.v[p] = ld_bf16x8(base + row * ld + k);
+        else
+            s.v[p] = zero_bf16x8();
+    }
+}
+__device__ __forceinline__ void lstore_kc(const Stage& s, char* tile, int tid) {
+    const int chunk = tid & 7;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = (tid >> 3) + 32 * p;
+        *reinterpret_cast<bf16x8*>(tile + kc_off(row, chunk)) = s.v[p];
+    }
+}
+// m-contiguous operand ([K][ld] with the tile's 128 m/n columns contiguous): thread t loads k rows (t>>4)+16p, chunk t&15.
+__device__ __forceinline__ void gload_mc(Stage& s, const bf16* base, int64_t ld, int64_t col0, int64_t ncols, int64_t k0,
+                                         int64_t K, int tid) {
+    const int c16 = tid & 15;
+    const int64_t col = col0 + c16 * 8;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t k = k0 + (tid >> 4) + 16 * p;
+        if (k < K && col < ncols)
+            s.v[p] = ld_bf16x8(base + k * ld + col);
+        else
+            s.v[p] = zero_bf16x8();
+    }
+}
+__device__ __forceinline__ void lstore_mc(const Stage& s, char* tile, int tid) {
+    const int c16 = tid & 15;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int krow = (tid >> 4) + 16 * p;
+        *reinterpret_cast<bf16x8*>(tile + mc_off(krow, c16 * 16)) = s.v[p];
+    }
+}
+
+// implicit-GEMM gather for NHWC convolution.  Row m = (img, oh, ow); k = (kh, kw, ci) with ci contiguous.
+struct ConvRows {
+    int64_t img_base[4];  // element offset of the image (img * H * W * C), or -1 if the row is out of range
+    int ih0[4], iw0[4];   // logical top-left input coordinate (oh*stride - pad, ow*stride - pad)
+};
+__device__ __forceinline__ void conv_rows_init(ConvRows& r, const ConvGeom& g, int64_t row0, int64_t M, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int64_t m = row0 + (tid >> 3) + 32 * p;
+        if (m < M) {
+            const int64_t hw = (int64_t)g.OH * g.OW;
+            const int64_t img = m / hw;
+            const int rem = (int)(m - img * hw);
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            r.img_base[p] = img * (int64_t)g.H * g.W * g.C;
+            r.ih0[p] = oh * g.stride - g.pad;
+            r.iw0[p] = ow * g.stride - g.pad;
+        } else {
+            r.img_base[p] = -1;
+            r.ih0[p] = 0;
+            r.iw0[p] = 0;
+        }
+    }
+}
+__device__ __forceinline__ void gload_conv(Stage& s, const bf16* base, const ConvGeom& g, const ConvRows& r, int64_t k0,
+                                           int64_t K, int tid) {
+    const int64_t k = k0 + (tid & 7) * 8;
+    const bool kvalid = k < K;
+    const int tap = kvalid ? (int)(k / g.C) : 0;
+    const int ci = kvalid ? (int)(k - (int64_t)tap * g.C) : 0;
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int ih = r.ih0[p] + kh, iw = r.iw0[p] + kw;
+        bool ok = kvalid && r.img_base[p] >= 0 && ih >= 0 && iw >= 0;
+        if (g.even_only) ok = ok && ((ih & 1) == 0) && ((iw & 1) == 0);
+        if (g.up_shift | g.even_only) {
+            ih >>= 1;
+            iw >>= 1;
+        }
+        ok = ok && ih < g.H && iw < g.W;
+        if (ok)
+            s.v[p] = ld_bf16x8(base + r.img_base[p] + ((int64_t)ih * g.W + iw) * g.C + ci);
+        else
+            s.v[p] = zero_bf16x8();
+    }
+}
+
+// ---- kernel -------------------------------------------------------------------------------------------------------
+template <int AL, int BL>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [buf][A 16 KiB | B 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+
+    // XCD-aware, grouped tile order
+    const int num_pid_m = (int)((P.M + BM - 1) / BM), num_pid_n = (int)((P.N + BN - 1) / BN);
+    const int nwg = num_pid_m * num_pid_n;
+    int wgid;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int in_group = GROUP_M * num_pid_n;
+    const int group_id = wgid / in_group;
+    const int first_m = group_id * GROUP_M;
+    const int gsz = min(num_pid_m - first_m, GROUP_M);
+    const int pid_m = first_m + (wgid % in_group) % gsz;
+    const int pid_n = (wgid % in_group) / gsz;
+    const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Stage sa, sb;
+    ConvRows crow;
+    if constexpr (AL == A_CONV) conv_rows_init(crow, P.cv, m0, P.M, tid);
+
+    auto gload = [&](int64_t k0) {
+        if constexpr (AL == A_K)
+            gload_kc(sa, P.A, P.lda, m0, P.M, k0, P.K, tid);
+        else if constexpr (AL == A_M)
+            gload_mc(sa, P.A, P.lda, m0, P.M, k0, P.K, tid);
+        else
+            gload_conv(sa, P.A, P.cv, crow, k0, P.K, tid);
+        if constexpr (BL == B_K)
+            gload_kc(sb, P.B, P.ldb, n0, P.N, k0, P.K, tid);
+        else
+            gload_mc(sb, P.B, P.ldb, n0, P.N, k0, P.K, tid);
+    };
+    auto lstore = [&](int buf) {
+        char* ta = smem + buf * 32768;
+        char* tb = ta + 16384;
+        if constexpr (AL == A_M)
+            lstore_mc(sa, ta, tid);
+        else
+            lstore_kc(sa, ta, tid);
+        if constexpr (BL == B_K)
+            lstore_kc(sb, tb, tid);
+        else
+            lstore_mc(sb, tb, tid);
+    };
+
+    const int nt = (int)((P.K + BK - 1) / BK);
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) gload((int64_t)(t + 1) * BK);
+        const char* ta = smem + (t & 1) * 32768;
+        const char* tb = ta + 16384;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (AL == A_M)
+                    fa[i] = frag_mc(ta, wm + i * 16, kk, lane);
+                else
+                    fa[i] = frag_kc(ta, wm + i * 16 + (lane & 15), kk, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (BL == B_K)
+                    fb[j] = frag_kc(tb, wn + j * 16 + (lane & 15), kk, lane);
+                else
+                    fb[j] = frag_mc(tb, wn + j * 16, kk, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) lstore((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds C[m][n..n+3], m = m0+wm+i*16+(lane&15), n = n0+wn+j*16+(lane>>4)*4
+    const bool vec_ok = ((P.N & 3) == 0) && ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = m0 + wm + i * 16 + (lane & 15);
+        if (m >= P.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = n0 + wn + j * 16 + (lane >> 4) * 4;
+            if (n >= P.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * P.alpha;
+            const int nvalid = (int)min((int64_t)4, P.N - n);
+            if (P.bias != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nvalid) v[r] += (float)P.bias[n + r];
+            }
+            if (P.epi == EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+            } else if (P.epi == EPI_QUICK_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+            } else if (P.epi == EPI_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+            }
+            if (vec_ok && nvalid == 4) {
+                if (P.residual != nullptr) {
+                    bf16x4 rv = ld_bf16x4(P.residual + m * P.ldr + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
+                if (P.out_f32) {
+                    float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n;
+                    f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
+                    if (P.accumulate) o += *reinterpret_cast<f32x4*>(cp);
+                    *reinterpret_cast<f32x4*>(cp) = o;
+                } else {
+                    bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n;
+                    if (P.accumulate) {
+                        bf16x4 c = ld_bf16x4(cp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)c[r];
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+                    st_bf16x4(cp, o);
+                }
+            } else {
+                for (int r = 0; r < nvalid; ++r) {
+                    float x = v[r];
+                    if (P.residual != nullptr) x += (float)P.residual[m * P.ldr + n + r];
+                    if (P.out_f32) {
+                        float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n + r;
+                        *cp = P.accumulate ? (*cp + x) : x;
+                    } else {
+                        bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n + r;
+                        *cp = (bf16)(P.accumulate ? ((float)*cp + x) : x);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int AL, int BL>
+int launch_gemm(const GemmParams& P, hipStream_t stream) {
+    const int64_t tiles = cdiv64(P.M, BM) * cdiv64(P.N, BN);
+    if (tiles <= 0) return DLLM_OK;
+    if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AL, BL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL>), dim3((unsigned)tiles), dim3(256), 65536, stream, P);
+    return dllm_check_launch();
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+// layout_a: 0 = A[m][k] k-contiguous (lda = row pitch), 1 = A stored [K][lda] with m contiguous.
+// layout_b: 0 = B given as [N][ldb] k-contiguous (nn.Linear weight), 1 = B stored [K][ldb] with n contiguous.
+// epi: 0 none, 1 exact-erf GELU, 2 quick-GELU, 3 SiLU.  out_dtype: DLLM_BF16 / DLLM_F32.
+int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
+                   int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
+                   int out_dtype, int accumulate, float alpha, void* stream) {
+    if (M < 0 || N < 0 || K < 0) return DLLM_ERR_SHAPE;
+    if (M == 0 || N == 0) return DLLM_OK;
+    if (!aligned16(A) || !aligned16(B)) return DLLM_ERR_ALIGN;
+    if ((lda & 7) || (ldb & 7)) return DLLM_ERR_ALIGN;
+    if (layout_a == A_K && (K & 7)) return DLLM_ERR_ALIGN;
+    if (layout_b == B_K && (K & 7)) return DLLM_ERR_ALIGN;
+    if (layout_a == A_M && (M & 7)) return DLLM_ERR_ALIGN;
+    if (layout_b == B_N && (N & 7)) return DLLM_ERR_ALIGN;
+    if (out_dtype != DLLM_BF16 && out_dtype != DLLM_F32) return DLLM_ERR_DTYPE;
+    GemmParams P{};
+    P.A = (const bf16*)A; P.B = (const bf16*)B; P.C = C; P.bias = (const bf16*)bias; P.residual = (const bf16*)residual;
+    P.M = M; P.N = N; P.K = K; P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldr = ldr;
+    P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = accumulate; P.alpha = alpha;
+    hipStream_t s = (hipStream_t)stream;
+    if (layout_a == A_K && layout_b == B_K) return launch_gemm<A_K, B_K>(P, s);
+    if (layout_a == A_K && layout_b == B_N) return launch_gemm<A_K, B_N>(P, s);
+    if (layout_a == A_M && layout_b == B_N) return launch_gemm<A_M, B_N>(P, s);
+    if (layout_a == A_M && layout_b == B_K) return launch_gemm<A_M, B_K>(P, s);
+    return DLLM_ERR_SHAPE;
+}
+
+// NHWC convolution as implicit GEMM: out[n,oh,ow,co] = sum_{kh,kw,ci} in[n,ih,iw,ci] * w[co,kh,kw,ci] (+bias, +residual).
+// x: [NB,H,W,C] bf16, w: [CO, KH*KW*C] bf16 (k-contiguous), out: [NB,OH,OW,CO].
+// up2: the logical input is the nearest-2x upsampling of x (Upsample2D + conv fused).
+// even_only: transposed gather used for the dgrad of a stride-2 conv (logical stride 1 over a zero-stuffed grid).
+int dllm_conv2d_nhwc_bf16(const void* x, const void* w, void* out, const void* bias, const void* residual, int NB, int H,
+                          int W, int C, int OH, int OW, int CO, int KH, int KW, int stride, int pad, int up2, int even_only,
+                          int epi, int out_dtype, void* stream) {
+    if (NB < 0 || H <= 0 || W <= 0 || C <= 0 || CO <= 0 || OH <= 0 || OW <= 0) return DLLM_ERR_SHAPE;
+    if (NB == 0) return DLLM_OK;
+    if ((C & 7) != 0) return DLLM_ERR_ALIGN;
+    if (!aligned16(x) || !aligned16(w)) return DLLM_ERR_ALIGN;
+    if (!((KH == 3 && KW == 3) || (KH == 1 && KW == 1))) return DLLM_ERR_SHAPE;
+    GemmParams P{};
+    P.A = (const bf16*)x; P.B = (const bf16*)w; P.C = out; P.bias = (const bf16*)bias; P.residual = (const bf16*)residual;
+    P.M = (int64_t)NB * OH * OW; P.N = CO; P.K = (int64_t)KH * KW * C;
+    P.lda = C; P.ldb = P.K; P.ldc = CO; P.ldr = CO;
+    P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = 0; P.alpha = 1.0f;
+    P.cv = ConvGeom{H, W, C, OH, OW, KH, KW, stride, pad, up2, even_only};
+    return launch_gemm<A_CONV, B_K>(P, (hipStream_t)stream);
+}
+
+}  // extern "C"

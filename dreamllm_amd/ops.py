@@ -1,0 +1,597 @@
+"""Python operators over the HIP C-ABI (`include/dreamllm_hip.h`): raw launches + torch.autograd Functions.
+
+PyTorch is plumbing here: it owns device memory and streams; every arithmetic op below is a hand-written gfx950
+kernel.  There is NO eager fallback -- a CPU tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import DLLM_BF16, DLLM_F32, check
+
+_vp = ctypes.c_void_p
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("dreamllm_amd ops run only on a ROCm device (gfx950); there is no CPU fallback")
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return DLLM_BF16
+    if t.dtype == torch.float32:
+        return DLLM_F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _bf16(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.bfloat16:
+            raise TypeError(f"expected bfloat16, got {t.dtype}")
+
+
+EPI = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3}
+
+# --------------------------------------------------------------------------------------------- raw launches
+
+
+def rmsnorm_fwd(x, w, eps, residual=None):
+    """-> (y, h, rstd); h = x + residual (or x itself).  modeling_dreamllm.py:86-91."""
+    _need_gpu(x, w, residual)
+    _bf16(x, w, residual)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    y = torch.empty_like(x2)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    h = x2
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, D)
+        if not r2.is_contiguous():
+            r2 = r2.contiguous()
+        h = torch.empty_like(x2)
+    check("dllm_rmsnorm_fwd", _p(x2), _p(r2), _p(w), _p(h) if residual is not None else None, _p(y), _p(rstd), rows, D,
+          float(eps), _stream())
+    return y.view(x.shape), h.view(x.shape), rstd
+
+
+def rmsnorm_bwd(dy, h, w, rstd, dh_in=None, need_dw=True):
+    _need_gpu(dy, h, w)
+    D = h.shape[-1]
+    dy2 = dy.reshape(-1, D).contiguous()
+    h2 = h.reshape(-1, D)
+    rows = h2.shape[0]
+    dx = torch.empty_like(h2)
+    dhi = dh_in.reshape(-1, D).contiguous() if dh_in is not None else None
+    dw = part = None
+    if need_dw:
+        nparts = _lib.call("dllm_norm_bwd_nparts", rows)
+        part = torch.empty(nparts, D, dtype=torch.float32, device=h.device)
+        dw = torch.empty(D, dtype=w.dtype, device=h.device)
+    check("dllm_rmsnorm_bwd", _p(dy2), _p(h2), _p(w), _p(rstd), _p(dhi), _p(dx), _p(part), _p(dw), _dt(w) if need_dw else 0,
+          rows, D, _stream())
+    return dx.view(h.shape), dw
+
+
+def layernorm_fwd(x, w, b, eps, save_stats=True):
+    _need_gpu(x, w, b)
+    _bf16(x, w, b)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    rows = x2.shape[0]
+    y = torch.empty_like(x2)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check("dllm_layernorm_fwd", _p(x2), _p(w), _p(b), _p(y), _p(mean), _p(rstd), rows, D, float(eps), _stream())
+    return y.view(x.shape), mean, rstd
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, need_dw=True):
+    D = x.shape[-1]
+    dy2 = dy.reshape(-1, D).contiguous()
+    x2 = x.reshape(-1, D).contiguous()
+    rows = x2.shape[0]
+    dx = torch.empty_like(x2)
+    dw = db = pw = pb = None
+    if need_dw:
+        nparts = _lib.call("dllm_norm_bwd_nparts", rows)
+        pw = torch.empty(nparts, D, dtype=torch.float32, device=x.device)
+        pb = torch.empty(nparts, D, dtype=torch.float32, device=x.device)
+        dw = torch.empty(D, dtype=w.dtype, device=x.device)
+        db = torch.empty(D, dtype=w.dtype, device=x.device)
+    check("dllm_layernorm_bwd", _p(dy2), _p(x2), _p(w), _p(mean), _p(rstd), _p(dx), _p(pw), _p(pb), _p(dw), _p(db),
+          _dt(w), rows, D, _stream())
+    return dx.view(x.shape), dw, db
+
+
+def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=torch.bfloat16, bias=None, residual=None,
+         ldr=0, epi=None, accumulate=False, alpha=1.0):
+    """C[M,N] = A*B; layout_a 0: A[m][k] k-contiguous, 1: stored [K][lda]; layout_b 0: B as [N][ldb], 1: [K][ldb]."""
+    _need_gpu(a, b, out, bias, residual)
+    _bf16(a, b, bias, residual)
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    check("dllm_gemm_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
+          ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),
+          _stream())
+    return out
+
+
+def _as2d(x):
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1 or (x2.shape[0] > 1 and x2.stride(0) % 8 != 0):
+        x2 = x2.contiguous()
+    return x2
+
+
+def linear_fwd(x, w, bias=None, epi=None, residual=None, out_dtype=torch.bfloat16):
+    """y = epi(x W^T + bias) + residual ; x [..., K], w [N, K] (nn.Linear layout)."""
+    x2 = _as2d(x)
+    M, K = x2.shape
+    N = w.shape[0]
+    r2 = None
+    if residual is not None:
+        r2 = _as2d(residual)
+    wc = w if w.is_contiguous() else w.contiguous()
+    y = gemm(x2, wc, M, N, K, x2.stride(0), K, 0, 0, bias=bias, residual=r2, ldr=r2.stride(0) if r2 is not None else 0,
+             epi=epi, out_dtype=out_dtype)
+    return y.view(*x.shape[:-1], N)
+
+
+def linear_dgrad(dy, w):
+    """dx = dy W ; dy [..., N], w [N, K]."""
+    d2 = _as2d(dy)
+    M, N = d2.shape
+    K = w.shape[1]
+    wc = w if w.is_contiguous() else w.contiguous()
+    dx = gemm(d2, wc, M, K, N, d2.stride(0), K, 0, 1)
+    return dx.view(*dy.shape[:-1], K)
+
+
+def linear_wgrad(dy, x, out=None, accumulate=False, out_dtype=torch.bfloat16):
+    """dW[N,K] = dy^T x ; dy [..., N], x [..., K]."""
+    d2 = _as2d(dy)
+    x2 = _as2d(x)
+    T, N = d2.shape
+    K = x2.shape[1]
+    return gemm(d2, x2, N, K, T, d2.stride(0), x2.stride(0), 1, 1, out=out, accumulate=accumulate, out_dtype=out_dtype)
+
+
+def colsum(dy, out_dtype=torch.bfloat16):
+    """bias gradient: sum over rows (fp32 accumulate).  Uses the norm partial-sum reducer on a [rows, N] view."""
+    d2 = _as2d(dy)
+    # tiny reduction: torch handles it (plumbing-level reduction over an existing buffer)
+    return d2.sum(dim=0, dtype=torch.float32).to(out_dtype)
+
+
+def attn_fwd(q, k, v, causal, scale=None, seqlens=None, need_lse=True):
+    """q [B,Sq,H,D], k/v [B,Sk,Hkv,D] (any batch/seq/head strides, d contiguous) -> o [B,Sq,H,D], lse [B,H,Sq]."""
+    _need_gpu(q, k, v)
+    _bf16(q, k, v)
+    B, Sq, H, D = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    if k.stride() != v.stride():
+        v = v.contiguous()
+        k = k.contiguous()
+    if q.stride(-1) != 1 or k.stride(-1) != 1:
+        raise ValueError("head dim must be contiguous")
+    scale = scale if scale is not None else 1.0 / math.sqrt(D)
+    o = torch.empty(B, Sq, H, D, dtype=q.dtype, device=q.device)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_lse else None
+    check("dllm_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), B, H, Hkv, Sq, Sk, D, q.stride(0), q.stride(1),
+          q.stride(2), k.stride(0), k.stride(1), k.stride(2), o.stride(0), o.stride(1), o.stride(2), float(scale),
+          int(causal), _stream())
+    return o, lse
+
+
+def attn_bwd(dout, q, k, v, o, lse, causal, scale=None, seqlens=None):
+    B, Sq, H, D = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    scale = scale if scale is not None else 1.0 / math.sqrt(D)
+    if k.stride() != v.stride():
+        raise ValueError("k and v must share strides")
+    dout = dout if (dout.stride(-1) == 1 and dout.stride() == o.stride()) else dout.contiguous()
+    if dout.stride() != o.stride():
+        o = o.contiguous()
+    dq = torch.empty(B, Sq, H, D, dtype=q.dtype, device=q.device)
+    dk = torch.empty(B, Sk, Hkv, D, dtype=q.dtype, device=q.device)
+    dv = torch.empty(B, Sk, Hkv, D, dtype=q.dtype, device=q.device)
+    delta = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
+    check("dllm_attn_bwd", _p(dout), _p(q), _p(k), _p(v), _p(o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(seqlens),
+          B, H, Hkv, Sq, Sk, D, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+          o.stride(0), o.stride(1), o.stride(2), float(scale), int(causal), _stream())
+    return dq, dk, dv
+
+
+def rope_(x, cos, sin, pos=None, backward=False):
+    """In-place rotary embedding on x [B,S,NH,D] view (d contiguous, uniform token stride).  cos/sin fp32 [P, D/2]."""
+    _need_gpu(x, cos, sin, pos)
+    _bf16(x)
+    B, S, NH, D = x.shape
+    if x.stride(3) != 1 or x.stride(0) != S * x.stride(1):
+        raise ValueError("rope_: x must have a uniform token stride")
+    if pos is not None:
+        pos = pos.expand(B, S).contiguous().view(-1)
+        if pos.dtype != torch.int64:
+            pos = pos.long()
+    check("dllm_rope", _p(x), _p(cos), _p(sin), _p(pos), B * S, S, NH, D, x.stride(1), x.stride(2), int(backward), _stream())
+    return x
+
+
+def glu_fwd(a, b, mode):
+    """mode 0: silu(a)*b (SwiGLU), mode 1: gelu(a)*b (GEGLU).  a, b: [..., F] views with unit inner stride."""
+    _need_gpu(a, b)
+    _bf16(a, b)
+    F = a.shape[-1]
+    a2, b2 = a.reshape(-1, F), b.reshape(-1, F)
+    M = a2.shape[0]
+    out = torch.empty(M, F, dtype=a.dtype, device=a.device)
+    check("dllm_glu_fwd", _p(a2), _p(b2), _p(out), M, F, a2.stride(0), b2.stride(0), F, mode, _stream())
+    return out.view(*a.shape[:-1], F)
+
+
+def glu_bwd(dout, a, b, mode, da=None, db=None):
+    F = a.shape[-1]
+    a2, b2 = a.reshape(-1, F), b.reshape(-1, F)
+    d2 = dout.reshape(-1, F)
+    if d2.stride(-1) != 1:
+        d2 = d2.contiguous()
+    M = a2.shape[0]
+    if da is None:
+        da = torch.empty(M, F, dtype=a.dtype, device=a.device)
+        db = torch.empty(M, F, dtype=a.dtype, device=a.device)
+    check("dllm_glu_bwd", _p(d2), _p(a2), _p(b2), _p(da), _p(db), M, F, d2.stride(0), a2.stride(0), b2.stride(0),
+          da.stride(0), db.stride(0), mode, _stream())
+    return da, db
+
+
+def gather_rows(table, idx):
+    _need_gpu(table, idx)
+    _bf16(table)
+    idx = idx.reshape(-1).contiguous()
+    n, D = idx.numel(), table.shape[1]
+    out = torch.empty(n, D, dtype=table.dtype, device=table.device)
+    check("dllm_gather_rows", _p(table), _p(idx), _p(out), n, D, table.stride(0), D, _stream())
+    return out
+
+
+def scatter_rows_(dst, idx, src):
+    """dst[idx[i]] = src[i] (idx unique)."""
+    _need_gpu(dst, idx, src)
+    _bf16(dst, src)
+    idx = idx.reshape(-1).contiguous()
+    src2 = src.reshape(-1, src.shape[-1])
+    if not src2.is_contiguous():
+        src2 = src2.contiguous()
+    check("dllm_scatter_rows", _p(src2), _p(idx), _p(dst), idx.numel(), dst.shape[1], src2.stride(0), dst.stride(0), _stream())
+    return dst
+
+
+def embedding_bwd(dy, ids, num_rows):
+    """Deterministic embedding gradient: sort ids, segment-sum rows in fp32."""
+    dy2 = dy.reshape(-1, dy.shape[-1])
+    if not dy2.is_contiguous():
+        dy2 = dy2.contiguous()
+    ids = ids.reshape(-1)
+    sorted_ids, order = torch.sort(ids, stable=True)
+    uid, counts = torch.unique_consecutive(sorted_ids, return_counts=True)
+    seg = torch.zeros(uid.numel() + 1, dtype=torch.int64, device=ids.device)
+    seg[1:] = torch.cumsum(counts, 0)
+    dtable = torch.zeros(num_rows, dy2.shape[1], dtype=dy.dtype, device=dy.device)
+    check("dllm_segment_sum_rows", _p(dy2), _p(order.contiguous()), _p(seg), _p(uid.contiguous()), _p(dtable), uid.numel(),
+          dy2.shape[1], dy2.stride(0), dtable.stride(0), _stream())
+    return dtable
+
+
+def cross_entropy_rows(logits, labels, dlogits=None, gscale=None):
+    """Per-row CE over fp32 logits [R, V]; labels int64 [R] (-100 ignored).  Optionally writes bf16 dlogits."""
+    _need_gpu(logits, labels)
+    if logits.dtype != torch.float32:
+        raise TypeError("cross_entropy_rows expects fp32 logits (reference: logits.float())")
+    R, V = logits.shape
+    loss_row = torch.empty(R, dtype=torch.float32, device=logits.device)
+    check("dllm_cross_entropy", _p(logits), _p(labels), _p(loss_row), _p(dlogits), _p(gscale), R, V, logits.stride(0),
+          dlogits.stride(0) if dlogits is not None else 0, _stream())
+    return loss_row
+
+
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _need_gpu(p, g, m, v)
+    check("dllm_adamw", _p(p), _p(g), _p(m), _p(v), p.numel(), _dt(p), _dt(m), float(lr), float(beta1), float(beta2),
+          float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+
+
+def sumsq_(x, out):
+    check("dllm_sumsq", _p(x), x.numel(), _dt(x), _p(out), _stream())
+
+
+# --------------------------------------------------------------------------------------------- autograd Functions
+
+
+class RMSNormFn(torch.autograd.Function):
+    """DreamLLMRMSNorm.forward (modeling_dreamllm.py:86-91)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        y, h, rstd = rmsnorm_fwd(x, weight, eps, None)
+        ctx.save_for_backward(x, weight, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, rstd = ctx.saved_tensors
+        dx, dw = rmsnorm_bwd(dy, x, weight, rstd, dh_in=None, need_dw=ctx.needs_input_grad[1])
+        return dx, dw, None
+
+
+class AddRMSNormFn(torch.autograd.Function):
+    """h = x + residual (decoder residual stream, modeling_dreamllm.py:632,638) fused with the RMSNorm that follows."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, eps):
+        y, h, rstd = rmsnorm_fwd(x, weight, eps, residual)
+        ctx.save_for_backward(h, weight, rstd)
+        return h, y
+
+    @staticmethod
+    def backward(ctx, dh, dy):
+        h, weight, rstd = ctx.saved_tensors
+        dx, dw = rmsnorm_bwd(dy, h, weight, rstd, dh_in=dh, need_dw=ctx.needs_input_grad[2])
+        return dx, dx, dw, None
+
+
+def rmsnorm(x, weight, eps):
+    return RMSNormFn.apply(x, weight, eps)
+
+
+def add_rmsnorm(x, residual, weight, eps):
+    """h = x + residual ; y = RMSNorm(h) -> (h, y)."""
+    return AddRMSNormFn.apply(x, residual, weight, eps)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        need = x.requires_grad or weight.requires_grad
+        y, mean, rstd = layernorm_fwd(x, weight, bias, eps, save_stats=need)
+        if need:
+            ctx.save_for_backward(x, weight, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        need_dw = ctx.needs_input_grad[1]
+        dx, dw, db = layernorm_bwd(dy, x, weight, mean, rstd, need_dw=need_dw)
+        return dx, dw, (db if ctx.needs_input_grad[2] else None), None
+
+
+def layernorm(x, weight, bias, eps):
+    return LayerNormFn.apply(x, weight, bias, eps)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T (+ bias) (+ residual): nn.Linear call sites of the hot path (q/k/v/o, gate/up/down, lm_head, projectors)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, out_fp32):
+        y = linear_fwd(x, weight, bias=bias, residual=residual, out_dtype=torch.float32 if out_fp32 else torch.bfloat16)
+        ctx.save_for_backward(x if weight.requires_grad else None, weight if x.requires_grad else None)
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.wshape = weight.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        if dy.dtype != torch.bfloat16:
+            dy = dy.to(torch.bfloat16)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = linear_dgrad(dy, weight)
+        if ctx.needs_input_grad[1]:
+            dw = linear_wgrad(dy, x)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy)
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres, None
+
+
+def linear(x, weight, bias=None, residual=None, out_fp32=False):
+    return LinearFn.apply(x, weight, bias, residual, out_fp32)
+
+
+class GLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, mode):
+        ctx.save_for_backward(a, b)
+        ctx.mode = mode
+        return glu_fwd(a, b, mode)
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        da, db = glu_bwd(dout, a, b, ctx.mode)
+        return da.view(a.shape), db.view(b.shape), None
+
+
+def swiglu(gate, up):
+    return GLUFn.apply(gate, up, 0)
+
+
+def geglu(gate, value):
+    return GLUFn.apply(gate, value, 1)
+
+
+class RoPEFn(torch.autograd.Function):
+    """apply_rotary_pos_emb (modeling_dreamllm.py:184-209) on q and k in place ([B,S,H,D] views of the QKV GEMM output)."""
+
+    @staticmethod
+    def forward(ctx, q, k, cos, sin, pos):
+        rope_(q, cos, sin, pos)
+        rope_(k, cos, sin, pos)
+        ctx.mark_dirty(q, k)
+        ctx.save_for_backward(cos, sin, pos)
+        return q, k
+
+    @staticmethod
+    def backward(ctx, dq, dk):
+        cos, sin, pos = ctx.saved_tensors
+        dq = dq.contiguous() if not _uniform_tok(dq) else dq.clone()
+        dk = dk.contiguous() if not _uniform_tok(dk) else dk.clone()
+        rope_(dq, cos, sin, pos, backward=True)
+        rope_(dk, cos, sin, pos, backward=True)
+        return dq, dk, None, None, None
+
+
+def _uniform_tok(x):
+    return x.stride(3) == 1 and x.stride(0) == x.shape[1] * x.stride(1)
+
+
+def rope(q, k, cos, sin, pos=None):
+    return RoPEFn.apply(q, k, cos, sin, pos)
+
+
+class FlashAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, causal, scale, seqlens):
+        need = q.requires_grad or k.requires_grad or v.requires_grad
+        o, lse = attn_fwd(q, k, v, causal, scale, seqlens, need_lse=need)
+        if need:
+            ctx.save_for_backward(q, k, v, o, lse, seqlens)
+        ctx.causal, ctx.scale = causal, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, o, lse, seqlens = ctx.saved_tensors
+        dq, dk, dv = attn_bwd(dout, q, k, v, o, lse, ctx.causal, ctx.scale, seqlens)
+        return dq, dk, dv, None, None, None
+
+
+def flash_attn(q, k, v, causal=False, scale=None, seqlens=None):
+    """q [B,Sq,H,D], k/v [B,Sk,Hkv,D] -> [B,Sq,H,D] (flash_attn_func layout, modeling_dreamllm.py:547-549)."""
+    return FlashAttnFn.apply(q, k, v, causal, scale, seqlens)
+
+
+class EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, ids):
+        ctx.save_for_backward(ids)
+        ctx.nrows = weight.shape[0]
+        return gather_rows(weight, ids).view(*ids.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        return embedding_bwd(dy, ids, ctx.nrows), None
+
+
+def embedding(weight, ids):
+    return EmbeddingFn.apply(weight, ids)
+
+
+class ScatterRowsFn(torch.autograd.Function):
+    """Multimodal splice (modeling_dreamllm.py:1081-1141): base[idx[i]] = rows[i], as ONE index-scatter kernel."""
+
+    @staticmethod
+    def forward(ctx, base, idx, rows):
+        out = base.clone() if base.requires_grad or True else base
+        scatter_rows_(out.view(-1, out.shape[-1]), idx, rows)
+        ctx.save_for_backward(idx)
+        ctx.rows_shape = rows.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        d2 = dout.reshape(-1, dout.shape[-1])
+        drows = gather_rows(d2, idx).view(ctx.rows_shape) if ctx.needs_input_grad[2] else None
+        dbase = None
+        if ctx.needs_input_grad[0]:
+            dbase = dout.clone()
+            zeros = torch.zeros(idx.numel(), dout.shape[-1], dtype=dout.dtype, device=dout.device)
+            scatter_rows_(dbase.view(-1, dout.shape[-1]), idx, zeros)
+        return dbase, None, drows
+
+
+def scatter_rows(base, idx, rows):
+    return ScatterRowsFn.apply(base, idx, rows)
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """out[i] = x[idx[i]] with unique idx (dream-query hidden-state gather, modeling_dreamllm.py:1399-1418)."""
+
+    @staticmethod
+    def forward(ctx, x2d, idx):
+        ctx.save_for_backward(idx)
+        ctx.shape = x2d.shape
+        return gather_rows(x2d, idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dx = torch.zeros(ctx.shape, dtype=dout.dtype, device=dout.device)
+        scatter_rows_(dx, idx, dout)
+        return dx, None
+
+
+def gather_rows_unique(x2d, idx):
+    return GatherRowsFn.apply(x2d, idx)
+
+
+class LMHeadCEFn(torch.autograd.Function):
+    """lm_head + fp32 logits + shifted masked CE (modeling_dreamllm.py:1452-1470) as one differentiable unit.
+
+    hidden [R, d] bf16, weight [V, d] bf16, labels int64 [R] (already shifted; -100 ignored).
+    Returns (loss, logits_fp32).  The fp32 logits come straight from the fp32 MFMA accumulators.  Backward recomputes
+    the softmax from the saved logits and emits bf16 dlogits scaled by dloss / n_valid read from a device scalar
+    (no host sync), then two GEMMs.
+    """
+
+    @staticmethod
+    def forward(ctx, hidden, weight, labels):
+        logits = linear_fwd(hidden, weight, out_dtype=torch.float32)
+        loss_row = cross_entropy_rows(logits, labels)
+        nvalid = (labels != -100).sum()
+        denom = torch.clamp(nvalid, min=1).to(torch.float32)
+        ctx.save_for_backward(hidden, weight, logits, labels, denom)
+        ctx.mark_non_differentiable(logits)
+        return loss_row.sum() / denom, logits
+
+    @staticmethod
+    def backward(ctx, dloss, _dlogits_unused):
+        hidden, weight, logits, labels, denom = ctx.saved_tensors
+        gscale = (dloss.to(torch.float32) / denom).reshape(1).contiguous()
+        dlogits = torch.empty(logits.shape, dtype=torch.bfloat16, device=logits.device)
+        cross_entropy_rows(logits, labels, dlogits=dlogits, gscale=gscale)
+        dh = linear_dgrad(dlogits, weight) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(dlogits, hidden) if ctx.needs_input_grad[1] else None
+        return dh, dw, None
+
+
+def lm_head_ce(hidden2d, weight, labels1d):
+    return LMHeadCEFn.apply(hidden2d, weight, labels1d)

@@ -1,0 +1,387 @@
+"""`-m gpu` parity tests of the raw HIP kernels (called through the C-ABI) against the fp32 oracle on identical inputs.
+
+Tolerances (relative L2 against the fp32 oracle evaluated on the SAME bf16-representable inputs):
+  * bf16-output kernels: 4e-3  (one bf16 rounding is 2^-9/sqrt(3) = 1.1e-3 RMS; GEMM/attention add the rounding of the
+    bf16 probabilities / a second rounding in RMSNorm) -- every assert states its own bound;
+  * fp32-output kernels (logits, LSE, loss, rstd): 1e-4 or tighter.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _ops():
+    from dreamllm_amd import ops
+    return ops
+
+
+def rnd(*shape, scale=1.0, seed=None):
+    if seed is not None:
+        torch.manual_seed(seed)
+    return (torch.randn(*shape) * scale).to(BF)
+
+
+# ----------------------------------------------------------------------------- hardware-convention probes
+def test_probe_tr16_semantics():
+    """ds_read_b64_tr_b16: within a 16-lane group, lane i receives column i of the 4x16 row-major block whose 16
+    8-byte chunks are addressed by the group's lanes (chunk t = row t>>2, cols (t&3)*4..+3)."""
+    import ctypes
+    from dreamllm_amd import _lib
+    src = torch.arange(256, dtype=torch.int16, device=DEV)
+    out = torch.empty(256, dtype=torch.int16, device=DEV)
+    _lib.check("dllm_probe_tr16", ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got = out.cpu().view(64, 4)
+    exp = torch.empty(64, 4, dtype=torch.int16)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for j in range(4):
+            # block of group g starts at element g*64; row j (16 elements per row), column i
+            exp[lane, j] = g * 64 + j * 16 + i
+    assert torch.equal(got, exp), f"tr16 layout differs:\n{got[:20]}"
+
+
+def test_probe_mfma16_layout():
+    import ctypes
+    from dreamllm_amd import _lib
+    torch.manual_seed(1)
+    a = torch.randn(16, 32).to(BF)
+    b = torch.randn(16, 32).to(BF)  # [col][k]
+    out = torch.empty(256, dtype=torch.float32, device=DEV)
+    ad, bd = a.to(DEV), b.to(DEV)
+    _lib.check("dllm_probe_mfma16", ctypes.c_void_p(ad.data_ptr()), ctypes.c_void_p(bd.data_ptr()),
+               ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    got = out.cpu().view(64, 4)
+    ref = a.float() @ b.float().t()  # [row][col]
+    exp = torch.empty(64, 4)
+    for lane in range(64):
+        for r in range(4):
+            exp[lane, r] = ref[(lane >> 4) * 4 + r, lane & 15]
+    assert rel_l2(got, exp) < 1e-5
+
+
+# ----------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("rows,D", [(5, 96), (33, 1024), (64, 4096), (7, 5120), (130, 320)])
+def test_rmsnorm_fwd_bwd(rows, D):
+    ops = _ops()
+    torch.manual_seed(rows + D)
+    x = rnd(rows, D)
+    w = (1.0 + 0.1 * torch.randn(D)).to(BF)
+    dy = rnd(rows, D)
+    xr = x.float().requires_grad_(True)
+    wr = w.float().requires_grad_(True)
+    h = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-6)
+    yr = wr * h
+    yr.backward(dy.float())
+    y, _, rstd = ops.rmsnorm_fwd(x.to(DEV), w.to(DEV), 1e-6)
+    assert rel_l2(y, yr) < 4e-3
+    dx, dw = ops.rmsnorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), rstd)
+    assert rel_l2(dx, xr.grad) < 4e-3
+    assert rel_l2(dw, wr.grad) < 6e-3
+
+
+def test_rmsnorm_golden(golden):
+    """Bit-level check against the reference's own bf16 output (two roundings reproduced in the kernel)."""
+    ops = _ops()
+    g = golden("rmsnorm.pt")
+    y, _, _ = ops.rmsnorm_fwd(g["x"].to(BF).to(DEV), g["w"].to(BF).to(DEV), g["eps"])
+    ref_bf16 = g["y_bf16"]
+    mism = (y.cpu().float() - ref_bf16.float()).abs() > 0
+    # identical up to <=1 bf16 ulp on a handful of elements (reduction order of the fp32 mean)
+    assert mism.float().mean() < 0.02
+    assert rel_l2(y, g["y"]) < 4e-3
+
+
+def test_add_rmsnorm_fused():
+    ops = _ops()
+    x, r = rnd(40, 4096, seed=3), rnd(40, 4096)
+    w = (1.0 + 0.1 * torch.randn(4096)).to(BF)
+    y, h, rstd = ops.rmsnorm_fwd(x.to(DEV), w.to(DEV), 1e-5, residual=r.to(DEV))
+    href = (x.float() + r.float()).to(BF)
+    assert torch.equal(h.cpu(), href)
+    hr = href.float()
+    yr = w.float() * (hr * torch.rsqrt(hr.pow(2).mean(-1, keepdim=True) + 1e-5))
+    assert rel_l2(y, yr) < 4e-3
+
+
+@pytest.mark.parametrize("rows,D", [(9, 1024), (300, 320), (64, 1280)])
+def test_layernorm_fwd_bwd(rows, D):
+    ops = _ops()
+    torch.manual_seed(D)
+    x = rnd(rows, D)
+    w = (1.0 + 0.1 * torch.randn(D)).to(BF)
+    b = (0.1 * torch.randn(D)).to(BF)
+    dy = rnd(rows, D)
+    xr, wr, br = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    yr = F.layer_norm(xr, (D,), wr, br, 1e-5)
+    yr.backward(dy.float())
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5)
+    assert rel_l2(y, yr) < 4e-3
+    dx, dw, db = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd)
+    assert rel_l2(dx, xr.grad) < 4e-3
+    assert rel_l2(dw, wr.grad) < 6e-3
+    assert rel_l2(db, br.grad) < 6e-3
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (130, 200, 264), (1, 64, 8), (777, 1000, 1032),
+                                   (512, 32008, 256)])
+def test_gemm_nt_forward(M, N, K):
+    ops = _ops()
+    torch.manual_seed(M + N + K)
+    x, w = rnd(M, K), rnd(N, K, scale=0.05)
+    ref = x.float() @ w.float().t()
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV))
+    assert y.shape == (M, N)
+    assert rel_l2(y, ref) < 4e-3
+    y32 = ops.linear_fwd(x.to(DEV), w.to(DEV), out_dtype=torch.float32)
+    assert rel_l2(y32, ref) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 264, 520), (64, 4096, 1024), (1000, 8, 136)])
+def test_gemm_dgrad_wgrad(M, N, K):
+    """dx = dy W (A_K, B_N: transpose reads on the weight) and dW = dy^T x (A_M, B_N: transpose reads on both)."""
+    ops = _ops()
+    torch.manual_seed(M * 3 + N)
+    dy, w, x = rnd(M, N), rnd(N, K, scale=0.05), rnd(M, K)
+    dx = ops.linear_dgrad(dy.to(DEV), w.to(DEV))
+    assert rel_l2(dx, dy.float() @ w.float()) < 4e-3
+    dw = ops.linear_wgrad(dy.to(DEV), x.to(DEV))
+    assert dw.shape == (N, K)
+    assert rel_l2(dw, dy.float().t() @ x.float()) < 4e-3
+    dw32 = ops.linear_wgrad(dy.to(DEV), x.to(DEV), out_dtype=torch.float32)
+    assert rel_l2(dw32, dy.float().t() @ x.float()) < 1e-5
+    acc = dw32.clone()
+    ops.linear_wgrad(dy.to(DEV), x.to(DEV), out=acc, accumulate=True)
+    assert rel_l2(acc, 2 * (dy.float().t() @ x.float())) < 1e-5
+
+
+@pytest.mark.parametrize("epi", [None, "gelu", "quick_gelu", "silu"])
+def test_gemm_epilogues(epi):
+    ops = _ops()
+    torch.manual_seed(5)
+    M, N, K = 200, 328, 256
+    x, w, b, r = rnd(M, K), rnd(N, K, scale=0.06), rnd(N), rnd(M, N)
+    z = x.float() @ w.float().t() + b.float()
+    if epi == "gelu":
+        z = F.gelu(z)
+    elif epi == "quick_gelu":
+        z = z * torch.sigmoid(1.702 * z)
+    elif epi == "silu":
+        z = F.silu(z)
+    ref = z + r.float()
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), bias=b.to(DEV), epi=epi, residual=r.to(DEV))
+    assert rel_l2(y, ref) < 4e-3
+
+
+def test_gemm_rejects_bad_shapes():
+    ops = _ops()
+    x, w = rnd(8, 12).to(DEV), rnd(16, 12).to(DEV)  # K = 12 not a multiple of 8
+    with pytest.raises(ValueError):
+        ops.linear_fwd(x, w)
+    with pytest.raises(RuntimeError):
+        ops.linear_fwd(rnd(8, 16), rnd(16, 16))  # CPU tensors: no fallback
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, causal, seqlen=None):
+    """fp32 oracle; q [B,Sq,H,D], k/v [B,Sk,Hkv,D] -> o [B,Sq,H,D], lse [B,H,Sq]."""
+    B, Sq, H, D = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    qf, kf, vf = q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)
+    if Hkv != H:
+        kf = kf.repeat_interleave(H // Hkv, 1)
+        vf = vf.repeat_interleave(H // Hkv, 1)
+    s = qf @ kf.transpose(2, 3) / math.sqrt(D)
+    if causal:
+        m = torch.ones(Sq, Sk, dtype=torch.bool).tril(Sk - Sq)
+        s = s.masked_fill(~m, float("-inf"))
+    if seqlen is not None:
+        for b, L in enumerate(seqlen):
+            s[b, :, :, L:] = float("-inf")
+    lse = torch.logsumexp(s, -1)
+    o = torch.softmax(s, -1) @ vf
+    return o.transpose(1, 2), lse
+
+
+@pytest.mark.parametrize("B,H,Hkv,Sq,Sk,D,causal", [
+    (2, 4, 4, 128, 128, 128, True),
+    (1, 2, 2, 300, 300, 128, True),
+    (2, 3, 3, 257, 257, 64, False),    # CLIP-ViT
+    (2, 5, 5, 192, 64, 64, False),     # UNet cross-attention over the 64 dream tokens
+    (1, 4, 2, 160, 160, 128, True),    # GQA
+    (1, 2, 2, 64, 200, 64, False),
+    (1, 1, 1, 1024, 1024, 64, False),
+])
+def test_attn_fwd(B, H, Hkv, Sq, Sk, D, causal):
+    ops = _ops()
+    torch.manual_seed(Sq + Sk + D)
+    q, k, v = rnd(B, Sq, H, D), rnd(B, Sk, Hkv, D), rnd(B, Sk, Hkv, D)
+    oref, lref = attn_ref(q, k, v, causal)
+    o, lse = ops.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), causal)
+    assert rel_l2(o, oref) < 6e-3   # bf16 output rounding + bf16 probabilities in the PV MFMA
+    assert rel_l2(lse, lref) < 1e-4
+
+
+def test_attn_fwd_strided_qkv_and_padding():
+    """q/k/v as strided views of one fused [B,S,3,H,D] buffer; right padding handled through seqlens."""
+    ops = _ops()
+    torch.manual_seed(11)
+    B, S, H, D = 3, 200, 4, 128
+    qkv = rnd(B, S, 3, H, D).to(DEV)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    lens = [200, 131, 64]
+    seqlens = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    o, lse = ops.attn_fwd(q, k, v, True, seqlens=seqlens)
+    oref, lref = attn_ref(q.cpu(), k.cpu(), v.cpu(), True, seqlen=lens)
+    for b, L in enumerate(lens):
+        assert rel_l2(o[b, :L], oref[b, :L]) < 6e-3
+        assert rel_l2(lse[b, :, :L], lref[b, :, :L]) < 1e-4
+        assert torch.count_nonzero(o[b, L:]) == 0  # pad_input semantics: zeros at padded positions
+
+
+def test_attn_fwd_outlier_rescale():
+    """Force the online-softmax rescale branch: one key dominates late in the sequence."""
+    ops = _ops()
+    torch.manual_seed(2)
+    B, S, H, D = 1, 512, 2, 128
+    q, k, v = rnd(B, S, H, D), rnd(B, S, H, D), rnd(B, S, H, D)
+    k[0, 400] = q[0, 450] * 4.0
+    oref, lref = attn_ref(q, k, v, True)
+    o, lse = ops.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), True)
+    assert rel_l2(o, oref) < 6e-3
+    assert rel_l2(lse, lref) < 1e-4
+
+
+# ----------------------------------------------------------------------------- elementwise / gather / loss / optimizer
+def test_rope_golden(golden):
+    ops = _ops()
+    g = golden("rope.pt")
+    from oracle import llm_ref
+    cos, sin = llm_ref.rope_tables(32, 64)
+    half = 16
+    # reference layout [B,H,S,D] -> ours [B,S,H,D]
+    q = g["q"].transpose(1, 2).contiguous().to(BF).to(DEV)
+    k = g["k"].transpose(1, 2).contiguous().to(BF).to(DEV)
+    qr, kr = llm_ref.apply_rope(g["q"].to(BF).float(), g["k"].to(BF).float(), cos, sin, g["pos"])
+    ct, st = cos[:, :half].contiguous().to(DEV), sin[:, :half].contiguous().to(DEV)
+    ops.rope_(q, ct, st, g["pos"].to(DEV))
+    ops.rope_(k, ct, st, g["pos"].to(DEV))
+    assert rel_l2(q.transpose(1, 2), qr) < 4e-3
+    assert rel_l2(k.transpose(1, 2), kr) < 4e-3
+    # backward = inverse rotation
+    ops.rope_(q, ct, st, g["pos"].to(DEV), backward=True)
+    assert rel_l2(q.transpose(1, 2), g["q"].to(BF).float()) < 6e-3
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_glu(mode):
+    ops = _ops()
+    torch.manual_seed(mode)
+    M, Fd = 70, 352
+    gu = rnd(M, 2 * Fd)
+    a, b = gu[:, :Fd], gu[:, Fd:]
+    d = rnd(M, Fd)
+    ar, br = a.float().requires_grad_(True), b.float().requires_grad_(True)
+    ref = (F.silu(ar) if mode == 0 else F.gelu(ar)) * br
+    ref.backward(d.float())
+    gd = gu.to(DEV)
+    out = ops.glu_fwd(gd[:, :Fd], gd[:, Fd:], mode)
+    assert rel_l2(out, ref) < 4e-3
+    da, db = ops.glu_bwd(d.to(DEV), gd[:, :Fd], gd[:, Fd:], mode)
+    assert rel_l2(da, ar.grad) < 4e-3
+    assert rel_l2(db, br.grad) < 4e-3
+
+
+def test_gather_scatter_embedding_bwd():
+    ops = _ops()
+    torch.manual_seed(0)
+    table = rnd(50, 64).to(DEV)
+    ids = torch.randint(0, 50, (4, 9), device=DEV)
+    out = ops.gather_rows(table, ids)
+    assert torch.equal(out, table[ids.view(-1)])
+    dst = torch.zeros(30, 64, dtype=BF, device=DEV)
+    idx = torch.tensor([3, 7, 29, 0], device=DEV)
+    src = rnd(4, 64).to(DEV)
+    ops.scatter_rows_(dst, idx, src)
+    ref = torch.zeros(30, 64, dtype=BF, device=DEV)
+    ref[idx] = src
+    assert torch.equal(dst, ref)
+    dy = rnd(36, 64).to(DEV)
+    dt = ops.embedding_bwd(dy, ids, 50)
+    ref = torch.zeros(50, 64, dtype=torch.float32, device=DEV).index_add_(0, ids.view(-1), dy.float())
+    assert rel_l2(dt, ref) < 4e-3
+
+
+def test_cross_entropy():
+    ops = _ops()
+    torch.manual_seed(4)
+    R, V = 37, 32008
+    logits = (torch.randn(R, V) * 2).to(DEV)
+    labels = torch.randint(0, V, (R,), device=DEV)
+    labels[::5] = -100
+    lr = logits.detach().cpu().requires_grad_(True)
+    per = F.cross_entropy(lr, labels.cpu(), reduction="none", ignore_index=-100)
+    nvalid = (labels != -100).sum().item()
+    (per.sum() / nvalid).backward()
+    loss_row = ops.cross_entropy_rows(logits, labels)
+    assert rel_l2(loss_row, per) < 1e-5
+    dl = torch.empty(R, V, dtype=BF, device=DEV)
+    gs = torch.tensor([1.0 / nvalid], device=DEV)
+    ops.cross_entropy_rows(logits, labels, dlogits=dl, gscale=gs)
+    assert rel_l2(dl, lr.grad) < 4e-3
+
+
+def test_adamw_matches_torch():
+    ops = _ops()
+    torch.manual_seed(9)
+    n = 10000
+    p0, g = torch.randn(n), torch.randn(n) * 0.1
+    pt = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    p = p0.clone().to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        pt.grad = g.clone() * step
+        opt.step()
+        ops.adamw_(p, (g * step).to(DEV), m, v, 1e-2, 0.9, 0.98, 1e-8, 0.1, step)
+    assert rel_l2(p, pt) < 1e-5
+    # bf16 params + bf16 state (the reference's dtype choice, projects/dreamllm/train.py:66-71,170)
+    pb = p0.to(BF).to(DEV)
+    mb, vb = torch.zeros(n, dtype=BF, device=DEV), torch.zeros(n, dtype=BF, device=DEV)
+    ops.adamw_(pb, g.to(BF).to(DEV), mb, vb, 1e-2, 0.9, 0.98, 1e-8, 0.1, 1)
+    ref = torch.optim.AdamW([p0.to(BF).clone().requires_grad_(True)], lr=1e-2)
+    assert torch.isfinite(pb.float()).all()
+
+
+# ----------------------------------------------------------------------------- autograd wrappers
+def test_linear_autograd_and_lm_head_ce():
+    ops = _ops()
+    torch.manual_seed(6)
+    T, d, V = 96, 128, 1000
+    h = rnd(T, d)
+    w = rnd(V, d, scale=0.05)
+    labels = torch.randint(0, V, (T,))
+    labels[:7] = -100
+    hr, wr = h.float().requires_grad_(True), w.float().requires_grad_(True)
+    lref = F.cross_entropy(hr @ wr.t(), labels, ignore_index=-100)
+    (lref * 3.0).backward()
+    hg, wg = h.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    loss, logits = ops.lm_head_ce(hg, wg, labels.to(DEV))
+    (loss * 3.0).backward()
+    assert abs(loss.item() - lref.item()) < 1e-4 * abs(lref.item()) + 1e-5
+    assert rel_l2(logits, (hr @ wr.t())) < 1e-5
+    assert rel_l2(hg.grad, hr.grad) < 6e-3
+    assert rel_l2(wg.grad, wr.grad) < 6e-3
