@@ -385,3 +385,68 @@ def test_linear_autograd_and_lm_head_ce():
     assert rel_l2(logits, (hr @ wr.t())) < 1e-5
     assert rel_l2(hg.grad, hr.grad) < 6e-3
     assert rel_l2(wg.grad, wr.grad) < 6e-3
+
+
+# ----------------------------------------------------------------------------- attention backward
+@pytest.mark.parametrize("B,H,Hkv,Sq,Sk,D,causal", [
+    (2, 4, 4, 128, 128, 128, True),
+    (1, 2, 2, 300, 300, 128, True),
+    (2, 3, 3, 257, 257, 64, False),
+    (2, 5, 5, 192, 64, 64, False),
+    (1, 4, 2, 160, 160, 128, True),
+    (1, 2, 2, 64, 200, 64, False),
+    (1, 2, 1, 200, 200, 64, True),
+])
+def test_attn_bwd(B, H, Hkv, Sq, Sk, D, causal):
+    """dQ/dK/dV against fp32 autograd of the oracle attention.  Bound 1.5e-2: P and dS enter the MFMAs as bf16."""
+    ops = _ops()
+    torch.manual_seed(Sq * 7 + Sk + D)
+    q, k, v, do = rnd(B, Sq, H, D), rnd(B, Sk, Hkv, D), rnd(B, Sk, Hkv, D), rnd(B, Sq, H, D)
+    qr, kr, vr = (x.float().requires_grad_(True) for x in (q, k, v))
+    oref, _ = attn_ref(qr, kr, vr, causal)
+    oref.backward(do.float())
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse = ops.attn_fwd(qd, kd, vd, causal)
+    dq, dk, dv = ops.attn_bwd(do.to(DEV), qd, kd, vd, o, lse, causal)
+    assert rel_l2(dq, qr.grad) < 1.5e-2
+    assert rel_l2(dk, kr.grad) < 1.5e-2
+    assert rel_l2(dv, vr.grad) < 1.5e-2
+
+
+def test_attn_bwd_padding_and_strided():
+    ops = _ops()
+    torch.manual_seed(21)
+    B, S, H, D = 2, 200, 2, 128
+    qkv = rnd(B, S, 3, H, D)
+    lens = [200, 90]
+    do = rnd(B, S, H, D)
+    qr, kr, vr = (qkv[:, :, i].float().requires_grad_(True) for i in range(3))
+    oref, _ = attn_ref(qr, kr, vr, True, seqlen=lens)
+    mask = torch.zeros(B, S, 1, 1)
+    for b, L in enumerate(lens):
+        mask[b, :L] = 1
+    (oref * mask).backward(do.float())
+    qd = qkv.to(DEV)
+    q, k, v = qd[:, :, 0], qd[:, :, 1], qd[:, :, 2]
+    seqlens = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    o, lse = ops.attn_fwd(q, k, v, True, seqlens=seqlens)
+    dq, dk, dv = ops.attn_bwd(do.to(DEV), q, k, v, o, lse, True, seqlens=seqlens)
+    for b, L in enumerate(lens):
+        assert rel_l2(dq[b, :L], qr.grad[b, :L]) < 1.5e-2
+        assert rel_l2(dk[b, :L], kr.grad[b, :L]) < 1.5e-2
+        assert rel_l2(dv[b, :L], vr.grad[b, :L]) < 1.5e-2
+        assert torch.count_nonzero(dq[b, L:]) == 0 and torch.count_nonzero(dk[b, L:]) == 0
+
+
+def test_flash_attn_autograd():
+    ops = _ops()
+    torch.manual_seed(8)
+    B, S, H, D = 1, 130, 2, 64
+    q, k, v = rnd(B, S, H, D), rnd(B, S, H, D), rnd(B, S, H, D)
+    qr, kr, vr = (x.float().requires_grad_(True) for x in (q, k, v))
+    oref, _ = attn_ref(qr, kr, vr, False)
+    oref.square().sum().backward()
+    qd, kd, vd = (x.to(DEV).requires_grad_(True) for x in (q, k, v))
+    o = ops.flash_attn(qd, kd, vd, causal=False)
+    o.float().square().sum().backward()
+    assert rel_l2(qd.grad, qr.grad) < 2e-2 and rel_l2(kd.grad, kr.grad) < 2e-2 and rel_l2(vd.grad, vr.grad) < 2e-2
