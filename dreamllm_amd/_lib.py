@@ -38,6 +38,10 @@ SIGNATURES = {
     "dllm_sumsq": [c_void_p, c_i64, c_int, c_void_p, c_void_p],
     "dllm_mse_sum": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p],
     "dllm_mse_bwd": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
+    "dllm_add_bcast": [c_void_p] * 3 + [c_i64, c_i64, c_void_p],
+    "dllm_add_rowgroup": [c_void_p] * 3 + [c_i64, c_i64, c_int, c_void_p],
+    "dllm_act_fwd": [c_void_p, c_void_p, c_i64, c_int, c_void_p],
+    "dllm_act_bwd": [c_void_p, c_void_p, c_void_p, c_i64, c_int, c_void_p],
     "dllm_probe_tr16": [c_void_p, c_void_p, c_void_p],
     "dllm_probe_mfma16": [c_void_p, c_void_p, c_void_p, c_void_p],
 }

@@ -262,6 +262,70 @@ __global__ __launch_bounds__(256) void mse_bwd_kernel(const bf16* __restrict__ a
         da[i] = (bf16)(((float)a[i] - b[i]) * gs);
 }
 
+// ------------------------------------------------------------------ add / broadcast add / stand-alone activations
+// out[i] = a[i] + b[i % period]  (period == n: plain add).  Used for residual adds outside a GEMM epilogue, the CLIP
+// position embedding and the per-(image,channel) time-embedding add of the UNet ResBlock (with row_period).
+__global__ __launch_bounds__(256) void add_bcast_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
+                                                        bf16* __restrict__ out, int64_t nvec, int64_t period_vec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 x = ld_bf16x8(a + i * 8), y = ld_bf16x8(b + (i % period_vec) * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)x[e] + (float)y[e]);
+        st_bf16x8(out + i * 8, o);
+    }
+}
+// out[n, r, c] = a[n, r, c] + b[n, c]   (rows_per_group rows share one b row): UNet time-embedding add on NHWC.
+__global__ __launch_bounds__(256) void add_rowgroup_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
+                                                           bf16* __restrict__ out, int64_t nvec, int vec_per_row,
+                                                           int64_t rows_per_group) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / vec_per_row;
+        const int c = (int)(i % vec_per_row);
+        const int64_t grp = row / rows_per_group;
+        const bf16x8 x = ld_bf16x8(a + i * 8), y = ld_bf16x8(b + (grp * vec_per_row + c) * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)x[e] + (float)y[e]);
+        st_bf16x8(out + i * 8, o);
+    }
+}
+template <int MODE>
+__device__ __forceinline__ float act_f(float x) {
+    return MODE == 1 ? gelu_erf_f(x) : (MODE == 2 ? quick_gelu_f(x) : silu_f(x));
+}
+template <int MODE>
+__device__ __forceinline__ float act_grad_f(float x) {
+    if (MODE == 1) return gelu_erf_grad_f(x);
+    if (MODE == 2) {
+        const float s = sigmoid_f(1.702f * x);
+        return s + 1.702f * x * s * (1.f - s);
+    }
+    const float s = sigmoid_f(x);
+    return s * (1.f + x * (1.f - s));
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ out, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 v = ld_bf16x8(x + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)act_f<MODE>((float)v[e]);
+        st_bf16x8(out + i * 8, o);
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                      bf16* __restrict__ dx, int64_t nvec) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 v = ld_bf16x8(x + i * 8), d = ld_bf16x8(dy + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)d[e] * act_grad_f<MODE>((float)v[e]));
+        st_bf16x8(dx + i * 8, o);
+    }
+}
+
 // ------------------------------------------------------------------ transpose-read semantics probe (test infrastructure)
 __global__ void probe_tr16_kernel(const short* __restrict__ in, short* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) short lds[64 * 4];
@@ -416,6 +480,45 @@ int dllm_mse_bwd(const void* pred, const float* target, int64_t n, const float* 
     if (n == 0) return DLLM_OK;
     hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16*)pred, target, n,
                        gscale, (bf16*)dpred);
+    return dllm_check_launch();
+}
+
+// out = a + b[i % period] ; n and period multiples of 8 (period == n => plain add)
+int dllm_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t period, void* stream) {
+    if (n < 0 || (n & 7) || period <= 0 || (period & 7)) return DLLM_ERR_SHAPE;
+    if (n == 0) return DLLM_OK;
+    hipLaunchKernelGGL(add_bcast_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)a,
+                       (const bf16*)b, (bf16*)out, n / 8, period / 8);
+    return dllm_check_launch();
+}
+// out[g, r, :] = a[g, r, :] + b[g, :]  with a viewed as [groups][rows_per_group][C]
+int dllm_add_rowgroup(const void* a, const void* b, void* out, int64_t groups, int64_t rows_per_group, int C, void* stream) {
+    if (groups < 0 || rows_per_group <= 0 || C <= 0 || (C & 7)) return DLLM_ERR_SHAPE;
+    const int64_t n = groups * rows_per_group * C;
+    if (n == 0) return DLLM_OK;
+    hipLaunchKernelGGL(add_rowgroup_kernel, dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)a,
+                       (const bf16*)b, (bf16*)out, n / 8, C / 8, rows_per_group);
+    return dllm_check_launch();
+}
+// mode: 1 exact GELU, 2 quick-GELU, 3 SiLU
+int dllm_act_fwd(const void* x, void* out, int64_t n, int mode, void* stream) {
+    if (n < 0 || (n & 7) || mode < 1 || mode > 3) return DLLM_ERR_SHAPE;
+    if (n == 0) return DLLM_OK;
+    const int g = grid_for(n / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 1) hipLaunchKernelGGL(act_fwd_kernel<1>, dim3(g), dim3(256), 0, s, (const bf16*)x, (bf16*)out, n / 8);
+    else if (mode == 2) hipLaunchKernelGGL(act_fwd_kernel<2>, dim3(g), dim3(256), 0, s, (const bf16*)x, (bf16*)out, n / 8);
+    else hipLaunchKernelGGL(act_fwd_kernel<3>, dim3(g), dim3(256), 0, s, (const bf16*)x, (bf16*)out, n / 8);
+    return dllm_check_launch();
+}
+int dllm_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int mode, void* stream) {
+    if (n < 0 || (n & 7) || mode < 1 || mode > 3) return DLLM_ERR_SHAPE;
+    if (n == 0) return DLLM_OK;
+    const int g = grid_for(n / 8);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 1) hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(g), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, n / 8);
+    else if (mode == 2) hipLaunchKernelGGL(act_bwd_kernel<2>, dim3(g), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, n / 8);
+    else hipLaunchKernelGGL(act_bwd_kernel<3>, dim3(g), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, n / 8);
     return dllm_check_launch();
 }
 

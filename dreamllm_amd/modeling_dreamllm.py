@@ -1,0 +1,737 @@
+"""DreamLLM decoder on hand-written gfx950 kernels -- API mirror of omni/models/dreamllm/modeling_dreamllm.py.
+
+Same class names, constructor kwargs, forward signatures, output dataclasses and state_dict keys as the reference
+(`model.layers.{i}.self_attn.{q,k,v,o}_proj.weight`, `...rotary_emb.inv_freq`, `model.embed_tokens.weight`,
+`model.norm.weight`, `lm_head.weight`, plugins under `model.{dream,clip_vision}_embedding.*` and
+`stable_diffusion_head.*`), so it drops in under omni/models/dreamllm.  What differs is *how* a layer executes:
+
+* one `torch.autograd.Function` per decoder layer with a hand-written backward.  Only x, (q,k,v) after RoPE, the
+  attention output + LSE, the post-attention residual stream and gate/up are kept (3.0 GB/layer at B=16,S=2048); the
+  RMSNorm outputs and the SwiGLU product are recomputed in backward (HBM-bound, <1 % of the layer) instead of the
+  reference's whole-layer gradient checkpointing (modeling_dreamllm.py:994-1003, +33 % FLOPs) -- 288 GB of HBM3E makes
+  the 98 GB of activations resident.
+* attention is always the causal flash kernel (the reference's DreamLLMFlashAttention2 semantics,
+  modeling_dreamllm.py:403-583); a 2-D right-padding mask becomes per-sequence lengths.
+* residual adds are GEMM epilogues; RoPE is applied in place on the QKV GEMM output ([B,S,H,D], no head transposes).
+* the multimodal splice (modeling_dreamllm.py:1081-1141) is one index-scatter per modality driven by index tensors.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any
+
+import torch
+import torch.nn.functional as F  # noqa: F401  (kept for API parity of the module namespace)
+from torch import nn
+from transformers import PreTrainedModel
+from transformers.utils import ModelOutput
+
+from . import ops
+from .configuration_dreamllm import DreamLLMConfig
+from .tokenization_dreamllm import (
+    DEFAULT_BOS_TOKEN,
+    DEFAULT_DREAM_END_TOKEN,
+    DEFAULT_DREAM_START_TOKEN,
+    DEFAULT_EOS_TOKEN,
+    DEFAULT_IMAGE_PATCH_TOKEN,
+    DEFAULT_IMAGE_START_TOKEN,
+)
+from .utils import FSDPMixin, deep_instantiate, logger
+
+try:  # registration drives weight-decay grouping in the reference trainer (modeling_dreamllm.py:94)
+    from transformers.pytorch_utils import ALL_LAYERNORM_LAYERS
+except Exception:  # pragma: no cover
+    ALL_LAYERNORM_LAYERS = []
+
+
+class DreamLLMRMSNorm(nn.Module):
+    """modeling_dreamllm.py:77-91."""
+
+    def __init__(self, hidden_size, eps=1e-6):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, hidden_states):
+        return ops.rmsnorm(hidden_states, self.weight, self.variance_epsilon)
+
+
+ALL_LAYERNORM_LAYERS.append(DreamLLMRMSNorm)
+
+
+class RotaryEmbedding(nn.Module):
+    """modeling_dreamllm.py:97-128.  `inv_freq` stays a persistent buffer (it is in the reference's state_dict); the
+    cos/sin cache is kept in fp32 as [max_pos, dim/2] (the two halves of the reference's table are identical)."""
+
+    def __init__(self, dim, max_position_embeddings=2048, base=10000, device=None, scaling_factor=1.0, scaling_type=None):
+        super().__init__()
+        self.dim = dim
+        self.max_position_embeddings = max_position_embeddings
+        self.base = base
+        self.scaling_factor = scaling_factor
+        self.scaling_type = scaling_type
+        inv_freq = 1.0 / (self.base ** (torch.arange(0, self.dim, 2).float().to(device) / self.dim))
+        self.register_buffer("inv_freq", inv_freq)
+        self._cache = {}  # device -> (seq_len, cos_half, sin_half); plain fp32 tensors, immune to model.to(bf16)
+
+    def _build(self, seq_len, device):
+        # inv_freq is recomputed in fp32 from (base, dim): the registered buffer may have been cast to bf16 by .to()
+        base = self.base
+        if self.scaling_type == "dynamic" and seq_len > self.max_position_embeddings:  # modeling_dreamllm.py:150-173
+            base = self.base * ((self.scaling_factor * seq_len / self.max_position_embeddings) - (self.scaling_factor - 1)) ** (
+                self.dim / (self.dim - 2))
+        inv_freq = 1.0 / (base ** (torch.arange(0, self.dim, 2, device=device).float() / self.dim))
+        t = torch.arange(seq_len, device=device, dtype=torch.float32)
+        if self.scaling_type == "linear":  # modeling_dreamllm.py:131-147
+            t = t / self.scaling_factor
+        freqs = torch.einsum("i,j->ij", t, inv_freq)
+        return freqs.cos().contiguous(), freqs.sin().contiguous()
+
+    def tables(self, seq_len, device):
+        """fp32 [>=seq_len, dim/2] cos and sin tables on `device`."""
+        key = str(torch.device(device))
+        ent = self._cache.get(key)
+        need = max(seq_len, self.max_position_embeddings)
+        if ent is None or ent[0] < need:
+            c, s = self._build(need, device)
+            ent = (need, c, s)
+            self._cache[key] = ent
+        return ent[1], ent[2]
+
+    def forward(self, x, seq_len=None):
+        """Reference-shaped output: (cos, sin) of shape [seq_len, dim] in x.dtype."""
+        c, s = self.tables(seq_len, x.device)
+        return torch.cat([c, c], -1)[:seq_len].to(x.dtype), torch.cat([s, s], -1)[:seq_len].to(x.dtype)
+
+
+# ----------------------------------------------------------------------------------------- fused decoder layer
+class _DecoderLayerFn(torch.autograd.Function):
+    """DreamLLMDecoderLayer.forward (modeling_dreamllm.py:622-640) with a hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, n_heads, n_kv, eps, want_kv):
+        B, S, Hd = x.shape
+        hd = Hd // n_heads
+        h, _, rstd1 = ops.rmsnorm_fwd(x, w_in, eps)
+        q = ops.linear_fwd(h, wq).view(B, S, n_heads, hd)
+        k = ops.linear_fwd(h, wk).view(B, S, n_kv, hd)
+        v = ops.linear_fwd(h, wv).view(B, S, n_kv, hd)
+        del h
+        ops.rope_(q, cos, sin, pos)
+        ops.rope_(k, cos, sin, pos)
+        need_bwd = any(ctx.needs_input_grad[:10])
+        o, lse = ops.attn_fwd(q, k, v, True, 1.0 / math.sqrt(hd), seqlens, need_lse=need_bwd)
+        x2 = ops.linear_fwd(o.view(B, S, Hd), wo, residual=x)
+        h2, _, rstd2 = ops.rmsnorm_fwd(x2, w_post, eps)
+        g = ops.linear_fwd(h2, wg)
+        u = ops.linear_fwd(h2, wu)
+        del h2
+        act = ops.glu_fwd(g, u, 0)
+        y = ops.linear_fwd(act, wd, residual=x2)
+        if need_bwd:
+            ctx.save_for_backward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, rstd1, q, k, v, o, lse,
+                                  x2, rstd2, g, u)
+            ctx.cfg = (n_heads, n_kv, eps)
+        if want_kv:
+            ctx.mark_non_differentiable(k, v)
+            return y, k, v
+        return y, None, None
+
+    @staticmethod
+    def backward(ctx, dy, _dk, _dv):
+        (x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, rstd1, q, k, v, o, lse, x2, rstd2, g,
+         u) = ctx.saved_tensors
+        n_heads, n_kv, eps = ctx.cfg
+        B, S, Hd = x.shape
+        hd = Hd // n_heads
+        need = ctx.needs_input_grad
+        dy = dy.contiguous()
+        # ---- MLP
+        d_act = ops.linear_dgrad(dy, wd)
+        dwd = None
+        if need[9]:
+            act = ops.glu_fwd(g, u, 0)  # recomputed, not stored
+            dwd = ops.linear_wgrad(dy, act)
+            del act
+        dg, du = ops.glu_bwd(d_act, g, u, 0)
+        del d_act
+        dwg = dwu = None
+        if need[7] or need[8]:
+            h2, _, _ = ops.rmsnorm_fwd(x2, w_post, eps)  # recomputed
+            if need[7]:
+                dwg = ops.linear_wgrad(dg, h2)
+            if need[8]:
+                dwu = ops.linear_wgrad(du, h2)
+            del h2
+        T = B * S
+        dh2 = ops.gemm(dg, wg, T, Hd, wg.shape[0], dg.stride(0), Hd, 0, 1)
+        ops.gemm(du, wu, T, Hd, wu.shape[0], du.stride(0), Hd, 0, 1, out=dh2, accumulate=True)
+        del dg, du
+        dx2, dw_post = ops.rmsnorm_bwd(dh2, x2, w_post, rstd2, dh_in=dy, need_dw=need[6])
+        del dh2
+        # ---- attention
+        do = ops.linear_dgrad(dx2, wo).view(B, S, n_heads, hd)
+        dwo = ops.linear_wgrad(dx2, o.view(B, S, Hd)) if need[5] else None
+        dq, dk, dv = ops.attn_bwd(do, q, k, v, o, lse, True, 1.0 / math.sqrt(hd), seqlens)
+        del do
+        ops.rope_(dq, cos, sin, pos, backward=True)
+        ops.rope_(dk, cos, sin, pos, backward=True)
+        dq2, dk2, dv2 = dq.view(T, -1), dk.view(T, -1), dv.view(T, -1)
+        dwq = dwk = dwv = None
+        if need[2] or need[3] or need[4]:
+            h, _, _ = ops.rmsnorm_fwd(x, w_in, eps)  # recomputed
+            if need[2]:
+                dwq = ops.linear_wgrad(dq2, h)
+            if need[3]:
+                dwk = ops.linear_wgrad(dk2, h)
+            if need[4]:
+                dwv = ops.linear_wgrad(dv2, h)
+            del h
+        dh = ops.gemm(dq2, wq, T, Hd, wq.shape[0], dq2.stride(0), Hd, 0, 1)
+        ops.gemm(dk2, wk, T, Hd, wk.shape[0], dk2.stride(0), Hd, 0, 1, out=dh, accumulate=True)
+        ops.gemm(dv2, wv, T, Hd, wv.shape[0], dv2.stride(0), Hd, 0, 1, out=dh, accumulate=True)
+        dx, dw_in = ops.rmsnorm_bwd(dh, x, w_in, rstd1, dh_in=dx2, need_dw=need[1])
+        return (dx.view(x.shape), dw_in, dwq, dwk, dwv, dwo, dw_post, dwg, dwu, dwd) + (None,) * 8
+
+
+class DreamLLMMLP(nn.Module):
+    """modeling_dreamllm.py:212-239 (pretraining_tp > 1 is a numerics knob of HF checkpoints; results are identical up to
+    summation order, so the single-GEMM path is always taken)."""
+
+    def __init__(self, config: DreamLLMConfig):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.intermediate_size = config.intermediate_size
+        self.gate_proj = nn.Linear(self.hidden_size, self.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(self.hidden_size, self.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(self.intermediate_size, self.hidden_size, bias=False)
+        if config.hidden_act != "silu":
+            raise ValueError("the HIP MLP kernel implements SwiGLU (hidden_act='silu') only")
+
+    def forward(self, x):
+        return ops.linear(ops.swiglu(ops.linear(x, self.gate_proj.weight), ops.linear(x, self.up_proj.weight)),
+                          self.down_proj.weight)
+
+
+class DreamLLMAttention(nn.Module):
+    """modeling_dreamllm.py:254-400 parameters; executes as causal flash attention (the reference's
+    DreamLLMFlashAttention2 semantics, modeling_dreamllm.py:403-583)."""
+
+    def __init__(self, config: DreamLLMConfig):
+        super().__init__()
+        self.config = config
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = self.hidden_size // self.num_heads
+        self.num_key_value_heads = config.num_key_value_heads
+        self.num_key_value_groups = self.num_heads // self.num_key_value_heads
+        self.max_position_embeddings = config.max_position_embeddings
+        self.rope_theta = config.rope_theta
+        self.is_causal = True
+        if (self.head_dim * self.num_heads) != self.hidden_size:
+            raise ValueError(
+                f"hidden_size must be divisible by num_heads (got `hidden_size`: {self.hidden_size} and `num_heads`: {self.num_heads})."
+            )
+        if self.head_dim not in (64, 128):
+            raise ValueError("the HIP attention kernels support head_dim 64 and 128")
+        if config.attention_bias:
+            raise ValueError("attention_bias=True is not supported by the fused decoder layer")
+        self.q_proj = nn.Linear(self.hidden_size, self.num_heads * self.head_dim, bias=False)
+        self.k_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=False)
+        self.v_proj = nn.Linear(self.hidden_size, self.num_key_value_heads * self.head_dim, bias=False)
+        self.o_proj = nn.Linear(self.num_heads * self.head_dim, self.hidden_size, bias=False)
+        self._init_rope()
+
+    def _init_rope(self):
+        """modeling_dreamllm.py:279-304."""
+        rs = self.config.rope_scaling
+        if rs is None:
+            self.rotary_emb = RotaryEmbedding(self.head_dim, self.max_position_embeddings, base=self.rope_theta)
+        else:
+            if rs["type"] not in ("linear", "dynamic"):
+                raise ValueError(f"Unknown RoPE scaling type {rs['type']}")
+            self.rotary_emb = RotaryEmbedding(self.head_dim, self.max_position_embeddings, base=self.rope_theta,
+                                              scaling_factor=rs["factor"], scaling_type=rs["type"])
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
+                use_cache=False, **kwargs):
+        """Stand-alone use (the decoder layer normally runs the fused function).  KV cache in the reference layout
+        [B, Hkv, S, D]."""
+        B, S, _ = hidden_states.shape
+        q = ops.linear(hidden_states, self.q_proj.weight).view(B, S, self.num_heads, self.head_dim)
+        k = ops.linear(hidden_states, self.k_proj.weight).view(B, S, self.num_key_value_heads, self.head_dim)
+        v = ops.linear(hidden_states, self.v_proj.weight).view(B, S, self.num_key_value_heads, self.head_dim)
+        past = past_key_value[0].shape[-2] if past_key_value is not None else 0
+        cos, sin = self.rotary_emb.tables(S + past, hidden_states.device)
+        if position_ids is None:
+            position_ids = torch.arange(past, past + S, device=hidden_states.device)[None]
+        q, k = ops.rope(q, k, cos, sin, position_ids)
+        if past_key_value is not None:
+            k = torch.cat([past_key_value[0].transpose(1, 2), k], dim=1)
+            v = torch.cat([past_key_value[1].transpose(1, 2), v], dim=1)
+        present = (k.transpose(1, 2), v.transpose(1, 2)) if use_cache else None
+        seqlens = _mask_to_seqlens(attention_mask) if past == 0 else None
+        o = ops.flash_attn(q, k, v, causal=True, seqlens=seqlens)
+        out = ops.linear(o.reshape(B, S, self.hidden_size), self.o_proj.weight)
+        return out, None, present
+
+
+DreamLLMFlashAttention2 = DreamLLMAttention  # same module: flash semantics are the only execution path
+
+
+def _mask_to_seqlens(attention_mask):
+    """2-D [B,S] mask with RIGHT padding (collator pads right: builder_dreamllm.py:466-482, tokenizer padding_side
+    'right' train.py:74) -> int32 lengths, computed on device (no host sync).  A 4-D additive mask is rejected."""
+    if attention_mask is None:
+        return None
+    if attention_mask.dim() != 2:
+        raise ValueError("the HIP decoder takes a 2-D padding mask (flash-attention path); 4-D additive masks are not supported")
+    return attention_mask.sum(dim=-1, dtype=torch.int32).contiguous()
+
+
+class DreamLLMDecoderLayer(nn.Module):
+    """modeling_dreamllm.py:586-654."""
+
+    def __init__(self, config: DreamLLMConfig):
+        super().__init__()
+        self.hidden_size = config.hidden_size
+        self.self_attn = DreamLLMAttention(config=config)
+        self.mlp = DreamLLMMLP(config)
+        self.input_layernorm = DreamLLMRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.post_attention_layernorm = DreamLLMRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
+                use_cache=False, **kwargs):
+        if output_attentions:
+            raise ValueError("output_attentions is not available on the flash-attention path (modeling_dreamllm.py:934-936)")
+        a = self.self_attn
+        if past_key_value is None:
+            B, S, _ = hidden_states.shape
+            cos, sin = a.rotary_emb.tables(S, hidden_states.device)
+            seqlens = kwargs.get("seqlens", None)
+            if seqlens is None:
+                seqlens = _mask_to_seqlens(attention_mask)
+            pos = None
+            if position_ids is not None:
+                pos = position_ids.expand(B, S).contiguous().view(-1).long()
+            y, k, v = _DecoderLayerFn.apply(
+                hidden_states.contiguous(), self.input_layernorm.weight, a.q_proj.weight, a.k_proj.weight, a.v_proj.weight,
+                a.o_proj.weight, self.post_attention_layernorm.weight, self.mlp.gate_proj.weight, self.mlp.up_proj.weight,
+                self.mlp.down_proj.weight, cos, sin, pos, seqlens, a.num_heads, a.num_key_value_heads,
+                self.input_layernorm.variance_epsilon, bool(use_cache))
+            outputs = (y,)
+            if use_cache:
+                outputs += ((k.transpose(1, 2), v.transpose(1, 2)),)
+            return outputs
+        # incremental decoding with a KV cache: module-by-module path (same kernels)
+        residual = hidden_states
+        h = self.input_layernorm(hidden_states)
+        h, _, present = a(h, attention_mask=attention_mask, position_ids=position_ids, past_key_value=past_key_value,
+                          use_cache=use_cache)
+        hidden_states = ops.add(residual, h)
+        residual = hidden_states
+        h = self.mlp(self.post_attention_layernorm(hidden_states))
+        hidden_states = ops.add(residual, h)
+        outputs = (hidden_states,)
+        if use_cache:
+            outputs += (present,)
+        return outputs
+
+
+@dataclass
+class BaseModelOutputWithPast(ModelOutput):
+    """modeling_dreamllm.py:763-800."""
+
+    last_hidden_state: torch.FloatTensor = None
+    past_key_values: tuple[tuple[torch.FloatTensor]] | None = None
+    hidden_states: tuple[torch.FloatTensor] | None = None
+    attentions: tuple[torch.FloatTensor] | None = None
+    additional_log_info: dict[str, Any] | None = None
+
+
+@dataclass
+class CausalLMOutputWithPast(ModelOutput):
+    """modeling_dreamllm.py:1172-1206."""
+
+    loss: torch.FloatTensor | None = None
+    logits: torch.FloatTensor = None
+    past_key_values: tuple[tuple[torch.FloatTensor]] | None = None
+    hidden_states: tuple[torch.FloatTensor] | None = None
+    attentions: tuple[torch.FloatTensor] | None = None
+    additional_log_info: dict[str, Any] | None = None
+
+
+class DreamLLMPreTrainedModel(PreTrainedModel, FSDPMixin):
+    """modeling_dreamllm.py:657-757."""
+
+    config_class = DreamLLMConfig
+    base_model_prefix = "model"
+    supports_gradient_checkpointing = True
+    _no_split_modules = ["DreamLLMDecoderLayer"]
+    _skip_keys_device_placement = "past_key_values"
+    _supports_flash_attn_2 = True
+    _keys_to_ignore_on_save = []
+
+    def init_plugin_modules(self):
+        pass
+
+    def _init_weights(self, module):
+        """modeling_dreamllm.py:674-683."""
+        std = self.config.initializer_range
+        if isinstance(module, nn.Linear):
+            module.weight.data.normal_(mean=0.0, std=std)
+            if module.bias is not None:
+                module.bias.data.zero_()
+        elif isinstance(module, nn.Embedding):
+            module.weight.data.normal_(mean=0.0, std=std)
+            if module.padding_idx is not None:
+                module.weight.data[module.padding_idx].zero_()
+
+
+def _special_id(config, token, nested=True):
+    d = config.special_tokens2ids_dict
+    return d["additional_special_tokens"][token] if nested else d[token]
+
+
+def _slot_indices(input_ids, start_id, length, max_slots=None):
+    """Flat row indices (into [B*S]) of the `length` positions that follow every `start_id` token, in (batch, position)
+    order -- the order the reference's Python loops visit them (modeling_dreamllm.py:1085-1098,1110-1139)."""
+    B, S = input_ids.shape
+    starts = torch.nonzero(input_ids.reshape(-1) == start_id, as_tuple=False).flatten()
+    if max_slots is not None:
+        starts = starts[:max_slots]
+    if starts.numel() > 0:
+        assert int(((starts % S) + length).max()) < S, "multimodal slot runs past the end of the sequence"
+    idx = starts[:, None] + 1 + torch.arange(length, device=input_ids.device)[None]
+    return idx.reshape(-1), starts.numel()
+
+
+class DreamLLMModel(DreamLLMPreTrainedModel):
+    """modeling_dreamllm.py:803-1169."""
+
+    def __init__(self, config: DreamLLMConfig):
+        super().__init__(config)
+        self.padding_idx = config.pad_token_id
+        self.vocab_size = config.vocab_size
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size, self.padding_idx)
+        self.layers = nn.ModuleList([DreamLLMDecoderLayer(config) for _ in range(config.num_hidden_layers)])
+        self.norm = DreamLLMRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self.gradient_checkpointing = False
+        self.post_init()
+
+    def init_plugin_modules(self):
+        """modeling_dreamllm.py:822-831."""
+        for name, init_kwargs in self.config.plugins_init_kwargs.items():
+            if self.config.plugins_type[name] == "embedding":
+                setattr(self, name, deep_instantiate(init_kwargs).to(self.device, dtype=self.dtype))
+                keys_to_ignore = [f"model.{name}.{key}" for key in getattr(self, name).state_dict().keys()]
+                self._keys_to_ignore_on_save.extend(keys_to_ignore)
+                logger.info(f"Added the prefix keys of `model.{name}` to the list of keys to ignore on save.")
+
+    def fsdp_ignored_modules(self) -> list:
+        ignored_modules = []
+        for name, _ in self.config.plugins_init_kwargs.items():
+            if self.config.plugins_type[name] == "embedding":
+                ignored_modules += getattr(self, name).fsdp_ignored_modules()
+        return ignored_modules
+
+    def get_input_embeddings(self):
+        return self.embed_tokens
+
+    def set_input_embeddings(self, value):
+        self.embed_tokens = value
+
+    def embed(self, input_ids):
+        return ops.embedding(self.embed_tokens.weight, input_ids)
+
+    def _forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
+                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, seqlens=None):
+        """modeling_dreamllm.py:846-1043."""
+        output_hidden_states = output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states
+        use_cache = use_cache if use_cache is not None else self.config.use_cache
+        return_dict = return_dict if return_dict is not None else getattr(self.config, "return_dict", True)
+        if input_ids is not None and inputs_embeds is not None:
+            raise ValueError("You cannot specify both input_ids and inputs_embeds at the same time")
+        elif input_ids is not None:
+            batch_size, seq_length = input_ids.shape[:2]
+        elif inputs_embeds is not None:
+            batch_size, seq_length = inputs_embeds.shape[:2]
+        else:
+            raise ValueError("You have to specify either input_ids or inputs_embeds")
+        past_len = past_key_values[0][0].shape[2] if past_key_values is not None else 0
+        if inputs_embeds is None:
+            inputs_embeds = self.embed(input_ids)
+        if position_ids is None and past_len > 0:
+            position_ids = torch.arange(past_len, seq_length + past_len, dtype=torch.long, device=inputs_embeds.device)[None]
+        if seqlens is None and attention_mask is not None and past_len == 0:
+            seqlens = _mask_to_seqlens(attention_mask)  # device-side; the all-ones case costs nothing extra in the kernel
+        if self.training and use_cache:
+            use_cache = False
+        hidden_states = inputs_embeds
+        all_hidden_states = () if output_hidden_states else None
+        next_decoder_cache = () if use_cache else None
+        additional_log_info = {}
+        for idx, decoder_layer in enumerate(self.layers):
+            if output_hidden_states:
+                all_hidden_states += (hidden_states,)
+            past_key_value = past_key_values[idx] if past_key_values is not None else None
+            layer_outputs = decoder_layer(hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                                          past_key_value=past_key_value, use_cache=use_cache, seqlens=seqlens)
+            hidden_states = layer_outputs[0]
+            if use_cache:
+                next_decoder_cache += (layer_outputs[1],)
+        hidden_states = self.norm(hidden_states)
+        if output_hidden_states:
+            all_hidden_states += (hidden_states,)
+        next_cache = next_decoder_cache if use_cache else None
+        if not return_dict:
+            return tuple(v for v in [hidden_states, next_cache, all_hidden_states, None, additional_log_info] if v is not None)
+        return BaseModelOutputWithPast(last_hidden_state=hidden_states, past_key_values=next_cache,
+                                       hidden_states=all_hidden_states, attentions=None,
+                                       additional_log_info=additional_log_info)
+
+    def forward(self, input_ids=None, images=None, images_dm=None, attention_mask=None, position_ids=None,
+                past_key_values=None, inputs_embeds=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, dream_index=None, image_index=None, seqlens=None):
+        """modeling_dreamllm.py:1045-1158.  `dream_index` / `image_index` (flat row indices from the data pipeline) are an
+        optional fast path that skips the device->host sync of locating the slots; semantics are unchanged."""
+        embed_tokens_backup = getattr(self, "embed_tokens_backup", None)
+        if embed_tokens_backup is not None:  # modeling_dreamllm.py:1059-1064
+            with torch.no_grad():
+                self.embed_tokens.weight[: -self.num_added_tokens] = embed_tokens_backup[: -self.num_added_tokens].data
+        if inputs_embeds is None and input_ids is not None:
+            inputs_embeds = self.embed(input_ids)
+        image_start_id = _special_id(self.config, DEFAULT_IMAGE_START_TOKEN)
+        dream_start_id = _special_id(self.config, DEFAULT_DREAM_START_TOKEN)
+        if (images is not None and not self.training and past_key_values is not None
+                and (input_ids is None or not bool((input_ids == image_start_id).any()))):
+            images = None  # modeling_dreamllm.py:1072-1079
+        B, S, H = inputs_embeds.shape if inputs_embeds is not None else (0, 0, 0)
+        # replace diffusion query tokens (modeling_dreamllm.py:1081-1099)
+        if images_dm is not None and inputs_embeds is not None and hasattr(self, "dream_embedding"):
+            nq = self.dream_embedding.embed_len
+            if dream_index is None:
+                dream_index, n_slots = _slot_indices(input_ids, dream_start_id, nq)
+            else:
+                n_slots = dream_index.numel() // nq
+            if n_slots > 0:
+                rows = self.dream_embedding(1).expand(n_slots, nq, H).reshape(n_slots * nq, H)
+                inputs_embeds = ops.scatter_rows(inputs_embeds.reshape(B * S, H), dream_index, rows).view(B, S, H)
+        # CLIP features (modeling_dreamllm.py:1102); the zero-image dummy pass is only needed to give every trainable
+        # parameter a gradient, so it is taken in training only (the reference re-runs CLIP on zeros per decoded token)
+        image_features = None
+        if hasattr(self, "clip_vision_embedding") and (images is not None or self.training):
+            image_features = self.clip_vision_embedding(images)
+        if inputs_embeds is not None:
+            if images is not None and image_features is not None:
+                npatch = image_features.shape[1]
+                if image_index is None:
+                    image_index, n_img = _slot_indices(input_ids, image_start_id, npatch, max_slots=image_features.shape[0])
+                else:
+                    n_img = image_index.numel() // npatch
+                rows = image_features[:n_img].reshape(n_img * npatch, H)
+                inputs_embeds = ops.scatter_rows(inputs_embeds.reshape(B * S, H), image_index, rows).view(B, S, H)
+            elif self.training and image_features is not None:
+                inputs_embeds = inputs_embeds + image_features  # dummy 0-valued term (modeling_dreamllm.py:1142-1144)
+        else:
+            inputs_embeds = image_features.unsqueeze(0)
+        return self._forward(input_ids=None, attention_mask=attention_mask, position_ids=position_ids,
+                             past_key_values=past_key_values, inputs_embeds=inputs_embeds, use_cache=use_cache,
+                             output_attentions=output_attentions, output_hidden_states=output_hidden_states,
+                             return_dict=return_dict, seqlens=seqlens)
+
+    def prepare_dream_queries_with_special_token(self, batch_size: int = 1):
+        """modeling_dreamllm.py:1161-1169."""
+        dream_start_id = _special_id(self.config, DEFAULT_DREAM_START_TOKEN)
+        dream_end_id = _special_id(self.config, DEFAULT_DREAM_END_TOKEN)
+        sp = self.embed(torch.as_tensor([[dream_start_id, dream_end_id]], device=self.device))
+        dream_queries = torch.cat([sp[..., :1, :], self.dream_embedding(), sp[..., 1:, :]], 1)
+        return dream_queries.repeat(batch_size, 1, 1).to(self.device)
+
+
+class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
+    """modeling_dreamllm.py:1209-1509 (+ prompt encoding / pipeline front-end 1598-1880)."""
+
+    _tied_weights_keys = {}
+
+    def __init__(self, config: DreamLLMConfig):
+        super().__init__(config)
+        self.model = DreamLLMModel(config)
+        self.vocab_size = config.vocab_size
+        self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
+        self.loss_weight_lm = config.loss_weight_lm
+        self.loss_weight_vm = config.loss_weight_vm
+        self.post_init()
+
+    def init_plugin_modules(self):
+        """modeling_dreamllm.py:1224-1235."""
+        self.model.init_plugin_modules()
+        for name, init_kwargs in self.config.plugins_init_kwargs.items():
+            if self.config.plugins_type[name] == "head":
+                setattr(self, name, deep_instantiate(init_kwargs).to(self.device, dtype=self.dtype))
+                keys_to_ignore = [f"{name}.{key}" for key in getattr(self, name).state_dict().keys()]
+                self._keys_to_ignore_on_save.extend(keys_to_ignore)
+                logger.info(f"Added the prefix keys of `{name}` to the list of keys to ignore on save.")
+
+    def fsdp_ignored_modules(self) -> list:
+        ignored_modules = self.model.fsdp_ignored_modules()
+        for name, _ in self.config.plugins_init_kwargs.items():
+            if self.config.plugins_type[name] == "head":
+                ignored_modules += getattr(self, name).fsdp_ignored_modules()
+        return ignored_modules
+
+    def get_input_embeddings(self):
+        return self.model.embed_tokens
+
+    def set_input_embeddings(self, value):
+        self.model.embed_tokens = value
+
+    def get_output_embeddings(self):
+        return self.lm_head
+
+    def set_output_embeddings(self, new_embeddings):
+        self.lm_head = new_embeddings
+
+    def set_decoder(self, decoder):
+        self.model = decoder
+
+    def get_decoder(self):
+        return self.model
+
+    def forward(self, input_ids=None, images=None, images_dm=None, attention_mask=None, position_ids=None,
+                past_key_values=None, inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
+                output_hidden_states=None, return_dict=None, dream_index=None, image_index=None, seqlens=None):
+        """modeling_dreamllm.py:1353-1509."""
+        if input_ids is not None:
+            assert (
+                input_ids.shape[1] <= self.config.max_position_embeddings
+            ), f"the sequence length should be less than model max length {self.config.max_position_embeddings}"
+        output_hidden_states = output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states
+        return_dict = return_dict if return_dict is not None else getattr(self.config, "return_dict", True)
+        if dream_index is None and images_dm is not None and input_ids is not None and hasattr(self.model, "dream_embedding"):
+            dream_index, _ = _slot_indices(input_ids, _special_id(self.config, DEFAULT_DREAM_START_TOKEN),
+                                           self.model.dream_embedding.embed_len)
+        outputs = self.model(input_ids=input_ids, images=images, images_dm=images_dm, attention_mask=attention_mask,
+                             position_ids=position_ids, past_key_values=past_key_values, inputs_embeds=inputs_embeds,
+                             use_cache=use_cache, output_attentions=output_attentions,
+                             output_hidden_states=output_hidden_states, return_dict=True, dream_index=dream_index,
+                             image_index=image_index, seqlens=seqlens)
+        hidden_states = outputs.last_hidden_state
+        B, S, H = hidden_states.shape
+
+        # Let's train diffusion!  (modeling_dreamllm.py:1397-1445)
+        vm_loss = 0.0
+        head = getattr(self, "stable_diffusion_head", None)
+        if self.training and images_dm is not None and head is not None:
+            nq = self.model.dream_embedding.embed_len
+            n_slots = min(dream_index.numel() // nq, images_dm.shape[0])
+            enc = ops.gather_rows_unique(hidden_states.reshape(B * S, H), dream_index[: n_slots * nq]).view(n_slots, nq, H)
+            u_enc = None
+            if head.drop_prob is not None:  # modeling_dreamllm.py:1420-1439
+                bos_id = _special_id(self.config, DEFAULT_BOS_TOKEN, nested=False)
+                eos_id = _special_id(self.config, DEFAULT_EOS_TOKEN, nested=False)
+                ds = _special_id(self.config, DEFAULT_DREAM_START_TOKEN)
+                de = _special_id(self.config, DEFAULT_DREAM_END_TOKEN)
+                dp = _special_id(self.config, DEFAULT_IMAGE_PATCH_TOKEN)
+                u_ids = torch.tensor([[bos_id, ds] + [dp] * nq + [de, eos_id]], device=hidden_states.device)
+                u_out = self.model(input_ids=u_ids, attention_mask=torch.ones_like(u_ids), use_cache=False, return_dict=True)
+                u_enc = u_out.last_hidden_state[:, 2: 2 + nq, :].repeat(n_slots, 1, 1)
+            vm_loss = head(images_dm, enc, u_enc)
+        elif self.training and head is not None:
+            vm_loss = head(images_dm, None, None, self.model.dream_embedding())
+
+        lm_loss = 0.0
+        if labels is not None:
+            # shift so that tokens < n predict n: row (b, s) is scored against labels[b, s+1]; the last row is ignored
+            shift = torch.cat([labels[:, 1:], labels.new_full((B, 1), -100)], dim=1).reshape(-1)
+            lm_loss, logits = ops.lm_head_ce(hidden_states.reshape(B * S, H), self.lm_head.weight, shift)
+            logits = logits.view(B, S, -1)
+        else:
+            logits = ops.linear(hidden_states, self.lm_head.weight, out_fp32=True)
+
+        if self.config.loss_scale_schedule == "l1_norm":
+            loss_scale = self.loss_weight_lm + self.loss_weight_vm
+        elif self.config.loss_scale_schedule == "l2_norm":
+            loss_scale = math.sqrt(self.loss_weight_lm**2 + self.loss_weight_vm**2)
+        else:
+            loss_scale = 1
+        # NaN guards (modeling_dreamllm.py:1479-1486) evaluated on device: no .cpu().item() sync in the step
+        if self.training and images is not None and torch.is_tensor(lm_loss):
+            lm_term = torch.where(torch.isnan(lm_loss), torch.zeros_like(lm_loss), lm_loss * self.loss_weight_lm)
+        else:
+            lm_term = lm_loss * self.loss_weight_lm
+        if self.training and images_dm is not None and torch.is_tensor(vm_loss):
+            vm_term = torch.where(torch.isnan(vm_loss), torch.zeros_like(vm_loss), vm_loss * self.loss_weight_vm)
+        else:
+            vm_term = vm_loss * self.loss_weight_vm
+        loss = (vm_term + lm_term) / loss_scale
+        if not torch.is_tensor(loss):
+            loss = None if labels is None and not self.training else torch.as_tensor(loss, device=hidden_states.device)
+
+        if not return_dict:
+            output = (logits,) + tuple(v for v in (outputs.past_key_values, outputs.hidden_states) if v is not None)
+            return (loss,) + output if loss is not None else output
+        additional_log_info = {
+            "lm_loss": lm_loss.detach() if torch.is_tensor(lm_loss) else lm_loss,
+            "vm_loss": vm_loss.detach() if torch.is_tensor(vm_loss) else vm_loss,
+        }
+        additional_log_info.update(outputs.additional_log_info or {})
+        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=outputs.past_key_values,
+                                      hidden_states=outputs.hidden_states, attentions=None,
+                                      additional_log_info=additional_log_info)
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):
+        """modeling_dreamllm.py:1511-1547."""
+        if past_key_values:
+            input_ids = input_ids[:, -1:]
+        position_ids = kwargs.get("position_ids", None)
+        if attention_mask is not None and position_ids is None:
+            position_ids = attention_mask.long().cumsum(-1) - 1
+            position_ids.masked_fill_(attention_mask == 0, 1)
+            if past_key_values:
+                position_ids = position_ids[:, -1].unsqueeze(-1)
+        if inputs_embeds is not None and past_key_values is None:
+            model_inputs = {"inputs_embeds": inputs_embeds}
+        else:
+            model_inputs = {"input_ids": input_ids}
+        model_inputs.update({"position_ids": position_ids, "past_key_values": past_key_values,
+                             "use_cache": kwargs.get("use_cache"), "attention_mask": attention_mask,
+                             "images": kwargs.get("images", None)})
+        return model_inputs
+
+    @torch.no_grad()
+    def greedy_generate(self, input_ids, max_new_tokens, images=None):
+        """Greedy decode with a KV cache: the loop of omni/eval/language_eval/modeling_dreamllm.py:76-97 with
+        temperature == 0 (argmax, :92)."""
+        out = self(input_ids=input_ids, images=images, use_cache=True, return_dict=True)
+        past = out.past_key_values
+        tokens = [out.logits[:, -1].argmax(-1)]
+        for _ in range(max_new_tokens - 1):
+            out = self(input_ids=tokens[-1][:, None], past_key_values=past, use_cache=True, return_dict=True)
+            past = out.past_key_values
+            tokens.append(out.logits[:, -1].argmax(-1))
+        return torch.cat([input_ids, torch.stack(tokens, 1)], dim=1)
+
+    @torch.no_grad()
+    def get_prompt_embeds(self, input_ids, attention_mask=None, images=None):
+        """Prompt -> dream-query hidden states (modeling_dreamllm.py:1598-1672): prefill the text with a KV cache, then run
+        [<dream_start>, 64 queries, <dream_end>] against it and take the query positions of the last hidden state."""
+        out = self(input_ids=input_ids, attention_mask=attention_mask, images=images, use_cache=True, return_dict=True)
+        dq = self.model.prepare_dream_queries_with_special_token(input_ids.shape[0]).to(self.dtype)
+        out2 = self.model._forward(inputs_embeds=dq, past_key_values=out.past_key_values, use_cache=False,
+                                   output_hidden_states=True, return_dict=True)
+        return out2.hidden_states[-1][:, 1:-1, :]
+
+    @torch.no_grad()
+    def stable_diffusion_pipeline(self, prompt_ids, negative_prompt_ids, guidance_scale=7.5, num_inference_steps=50,
+                                  height=None, width=None, generator=None, latents=None, output_type="latent",
+                                  guidance_rescale=0.0, **kw):
+        """modeling_dreamllm.py:1766-1880 on token ids (tokenisation is host-side, out of scope)."""
+        prompt_embeds = self.get_prompt_embeds(prompt_ids)
+        negative = self.get_prompt_embeds(negative_prompt_ids) if guidance_scale > 1.0 else None
+        return self.stable_diffusion_head.pipeline(
+            height=height, width=width, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
+            generator=generator, latents=latents, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative,
+            output_type=output_type, guidance_rescale=guidance_rescale, **kw)

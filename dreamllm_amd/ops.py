@@ -327,7 +327,92 @@ def sumsq_(x, out):
     check("dllm_sumsq", _p(x), x.numel(), _dt(x), _p(out), _stream())
 
 
+def add_bcast(a, b):
+    """a + b with b broadcast along the leading dims (b.numel() divides a.numel(); trailing layout identical)."""
+    _need_gpu(a, b)
+    _bf16(a, b)
+    a = a.contiguous()
+    b = b.contiguous()
+    out = torch.empty_like(a)
+    check("dllm_add_bcast", _p(a), _p(b), _p(out), a.numel(), b.numel(), _stream())
+    return out
+
+
+def add_rowgroup(a, b):
+    """a [G, R, C] + b [G, C] broadcast over R (UNet time-embedding add on NHWC activations)."""
+    _need_gpu(a, b)
+    _bf16(a, b)
+    a = a.contiguous()
+    b = b.contiguous()
+    G, C = b.shape
+    out = torch.empty_like(a)
+    check("dllm_add_rowgroup", _p(a), _p(b), _p(out), G, a.numel() // (G * C), C, _stream())
+    return out
+
+
+ACT = {"gelu": 1, "quick_gelu": 2, "silu": 3}
+
+
+def act_fwd(x, mode):
+    _need_gpu(x)
+    _bf16(x)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check("dllm_act_fwd", _p(x), _p(out), x.numel(), ACT[mode], _stream())
+    return out
+
+
+def act_bwd(dy, x, mode):
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    check("dllm_act_bwd", _p(dy), _p(x), _p(dx), x.numel(), ACT[mode], _stream())
+    return dx
+
+
 # --------------------------------------------------------------------------------------------- autograd Functions
+class AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.bshape = b.shape
+        ctx.same = a.shape == b.shape
+        return add_bcast(a, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        db = d if ctx.same else d.reshape(-1, *ctx.bshape).sum(0, dtype=torch.float32).to(d.dtype)
+        return d, db
+
+
+def add(a, b):
+    """bf16 add (b may be a trailing-shape broadcast of a)."""
+    return AddFn.apply(a, b)
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.mode = mode
+        return act_fwd(x, mode)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return act_bwd(dy, x, ctx.mode), None
+
+
+def gelu(x):
+    return ActFn.apply(x, "gelu")
+
+
+def silu(x):
+    return ActFn.apply(x, "silu")
+
+
+def quick_gelu(x):
+    return ActFn.apply(x, "quick_gelu")
+
 
 
 class RMSNormFn(torch.autograd.Function):

@@ -1,0 +1,87 @@
+"""Small host-side helpers the plugins rely on (mirrors of omni/utils/{fsdp_utils,modeling_utils,misc,torch_utils}.py)."""
+from __future__ import annotations
+
+import importlib
+import itertools
+import logging
+import os
+from collections.abc import Mapping
+
+import torch
+
+logger = logging.getLogger("dreamllm_amd")
+
+
+class FSDPMixin:
+    """omni/utils/fsdp_utils.py:18-20."""
+
+    def fsdp_ignored_modules(self) -> list:
+        return []
+
+
+def get_model_device(model: torch.nn.Module):
+    """omni/utils/modeling_utils.py:76."""
+    return next(itertools.chain(model.parameters(), model.buffers())).device
+
+
+def get_model_dtype(model: torch.nn.Module):
+    """omni/utils/modeling_utils.py:92: dtype of the first floating parameter/buffer."""
+    for t in itertools.chain(model.parameters(), model.buffers()):
+        if t.is_floating_point():
+            return t.dtype
+    return torch.float32
+
+
+def check_path_and_file(path, file):
+    """omni/utils/misc.py:226."""
+    if path is not None and os.path.isdir(path):
+        return os.path.isfile(os.path.join(path, file))
+    return False
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None):
+    """omni/utils/torch_utils.py:7-52: sample on the generator's device (CPU generator => CPU sample, then moved) so a
+    seed reproduces the same latents on every backend."""
+    device = device or torch.device("cpu")
+    if isinstance(generator, list):
+        shape1 = (1,) + tuple(shape[1:])
+        lat = [randn_tensor(shape1, g, device, dtype) for g in generator]
+        return torch.cat(lat, 0)
+    gdev = generator.device.type if generator is not None else torch.device(device).type
+    if gdev == "cpu":
+        return torch.randn(shape, generator=generator, device="cpu", dtype=dtype).to(device)
+    return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+
+
+def locate(name: str):
+    """omni/config/registry.py:30: resolve a dotted path to an object."""
+    parts = name.split(".")
+    for i in range(len(parts), 0, -1):
+        try:
+            obj = importlib.import_module(".".join(parts[:i]))
+        except ImportError:
+            continue
+        for p in parts[i:]:
+            obj = getattr(obj, p)
+        return obj
+    raise ImportError(f"cannot locate {name}")
+
+
+def target_to_string(t) -> str:
+    return t if isinstance(t, str) else f"{t.__module__}.{t.__qualname__}"
+
+
+def deep_instantiate(cfg):
+    """omni/config/instantiate.py:86-136 on plain dicts/lists: build objects from `_target_` dotted paths."""
+    if isinstance(cfg, list):
+        return [deep_instantiate(x) for x in cfg]
+    if isinstance(cfg, Mapping):
+        if "_target_" in cfg:
+            kw = {k: deep_instantiate(v) for k, v in cfg.items()}
+            cls = kw.pop("_target_")
+            if isinstance(cls, str):
+                cls = locate(cls)
+            assert callable(cls), f"_target_ {cls} does not define a callable object"
+            return cls(**kw)
+        return {k: deep_instantiate(v) for k, v in cfg.items()}
+    return cfg

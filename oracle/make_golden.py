@@ -16,8 +16,23 @@ from . import llm_ref, ref_loader
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
-TINY = dict(vocab_size=160, hidden_size=64, intermediate_size=192, num_hidden_layers=2, num_attention_heads=4,
+# head_dim = 64 (the HIP attention kernels support 64 and 128)
+TINY = dict(vocab_size=160, hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
             max_position_embeddings=128, rms_norm_eps=1e-6)
+HID = TINY["hidden_size"]
+
+
+def bf16r(t):
+    """round to bf16-representable fp32 so the HIP path (bf16 storage) sees bit-identical inputs/weights"""
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def init_params(module):
+    for p in module.parameters():
+        if p.dim() >= 2:
+            p.data = bf16r(torch.randn_like(p) * 0.05)
+        else:
+            p.data = bf16r(1.0 + 0.1 * torch.randn_like(p))
 # special ids laid out like tokenization_dreamllm.py:78-94 appended after a base vocab of 150 (+ [PAD])
 SPECIAL = {"pad": 150, "image": 151, "im_patch": 152, "im_start": 153, "im_end": 154, "dream": 155, "dream_start": 156,
            "dream_end": 157}
@@ -80,44 +95,40 @@ def main():
     save("rope.pt", dict(q=q, k=k, pos=pos, q_out=qo, k_out=ko))
 
     # ---- 3. decoder layer forward + backward
+    cfg_gqa = ref_loader.make_config(**{**TINY, "num_key_value_heads": 1})
     cfg = ref_loader.make_config(**TINY)
     cfg.special_tokens2ids_dict = special_tokens2ids_dict()
-    layer = m.DreamLLMDecoderLayer(cfg)
-    for p in layer.parameters():
-        if p.dim() == 2:
-            p.data.normal_(0, 0.05)
-        else:
-            p.data = 1.0 + 0.1 * torch.randn_like(p)
+    layer = m.DreamLLMDecoderLayer(cfg_gqa)
+    init_params(layer)
     B, S = 2, 24
-    x = torch.randn(B, S, 64, requires_grad=True)
+    x = bf16r(torch.randn(B, S, HID)).requires_grad_(True)
     mask = _prepare_4d_causal_attention_mask(None, (B, S), x, 0)
     pos = torch.arange(S)[None]
     y = layer(x, attention_mask=mask, position_ids=pos)[0]
-    dy = torch.randn_like(y)
+    dy = bf16r(torch.randn_like(y))
     y.backward(dy)
     sd = {k_: v.detach().clone() for k_, v in layer.state_dict().items()}
     grads = {n: p.grad.detach().clone() for n, p in layer.named_parameters()}
     cd = cfg_dict(cfg)
-    c2, s2 = llm_ref.rope_tables(16, 128)
-    y2 = llm_ref.decoder_layer(x.detach(), sd, "", cd, c2, s2, pos, llm_ref.causal_mask_4d(None, B, S, torch.float32))
+    cdg = cfg_dict(cfg_gqa)
+    c2, s2 = llm_ref.rope_tables(64, 128)
+    y2 = llm_ref.decoder_layer(x.detach(), sd, "", cdg, c2, s2, pos, llm_ref.causal_mask_4d(None, B, S, torch.float32))
     assert rel(y2, y.detach()) < 1e-5, rel(y2, y.detach())
-    save("decoder_layer.pt", dict(cfg=cd, sd=sd, x=x.detach(), y=y.detach(), dy=dy, dx=x.grad.detach(), grads=grads))
+    save("decoder_layer.pt", dict(cfg=cdg, sd={k_: v.to(torch.bfloat16) for k_, v in sd.items()}, x=x.detach(), y=y.detach(),
+                                  dy=dy, dx=x.grad.detach(), grads={k_: v.to(torch.bfloat16) for k_, v in grads.items()}))
 
     # ---- 4. DreamLLMModel._forward with right padding
     model = m.DreamLLMModel(cfg)
-    for n, p in model.named_parameters():
-        if p.dim() == 2:
-            p.data.normal_(0, 0.05)
-        else:
-            p.data = 1.0 + 0.1 * torch.randn_like(p)
-    emb = torch.randn(B, S, 64)
+    init_params(model)
+    emb = bf16r(torch.randn(B, S, HID))
     am = torch.ones(B, S, dtype=torch.long)
     am[1, 17:] = 0
     out = model._forward(inputs_embeds=emb, attention_mask=am).last_hidden_state.detach()
     sdm = {"model." + k_: v.detach().clone() for k_, v in model.state_dict().items()}
     out2 = llm_ref.model_forward(emb, sdm, cd, attention_mask=am)
     assert rel(out2[1, :17], out[1, :17]) < 1e-5 and rel(out2[0], out[0]) < 1e-5
-    save("model_forward.pt", dict(cfg=cd, sd=sdm, emb=emb, attention_mask=am, out=out))
+    save("model_forward.pt", dict(cfg=cd, sd={k_: (v.to(torch.bfloat16) if v.is_floating_point() else v) for k_, v in sdm.items()},
+                                  emb=emb, attention_mask=am, out=out))
 
     # ---- 5. DreamLLMForCausalMLM.forward with fake plugins (pins splice + dream-state gather + loss mix)
     class FakeDream(nn.Module):
@@ -125,7 +136,7 @@ def main():
 
         def __init__(self):
             super().__init__()
-            self.dream_queries = nn.Parameter(torch.randn(1, 4, 64) * 0.05)
+            self.dream_queries = nn.Parameter(bf16r(torch.randn(1, 4, HID) * 0.05))
 
         def forward(self, batch_size=1):
             return self.dream_queries.repeat(batch_size, 1, 1)
@@ -135,7 +146,7 @@ def main():
 
         def __init__(self):
             super().__init__()
-            self.proj = nn.Linear(8, 64)
+            self.proj = nn.Linear(8, HID)
 
         def forward(self, images=None):
             if images is None:
@@ -151,13 +162,11 @@ def main():
             return (encoder_hidden_states.float() * images).pow(2).mean()
 
     lm = m.DreamLLMForCausalMLM(cfg)
-    for n, p in lm.named_parameters():
-        if p.dim() == 2:
-            p.data.normal_(0, 0.05)
-        else:
-            p.data = 1.0 + 0.1 * torch.randn_like(p)
+    init_params(lm)
     lm.model.dream_embedding = FakeDream()
     lm.model.clip_vision_embedding = FakeClip()
+    init_params(lm.model.clip_vision_embedding)
+    lm.model.clip_vision_embedding.proj.bias.data = bf16r(0.1 * torch.randn(HID))
     lm.stable_diffusion_head = FakeHead()
     lm.train()
     S2 = 40
@@ -177,18 +186,20 @@ def main():
     am = torch.ones(B, S2, dtype=torch.long)
     am[1, 33:] = 0
     labels[am == 0] = -100
-    images = torch.randn(3, 6, 8)
-    images_dm = torch.randn(3, 4, 64)
+    images = bf16r(torch.randn(3, 6, 8))
+    images_dm = bf16r(torch.randn(3, 4, HID))
     out = lm(input_ids=ids, images=images, images_dm=images_dm, attention_mask=am, labels=labels, return_dict=True)
     out.loss.backward()
     sdl = {k_: v.detach().clone() for k_, v in lm.state_dict().items()}
-    g5 = dict(cfg=cd, sd=sdl, input_ids=ids, labels=labels, attention_mask=am, images=images, images_dm=images_dm,
+    b16 = lambda v: v.to(torch.bfloat16) if v.is_floating_point() else v
+    g5 = dict(cfg=cd, sd={k_: b16(v) for k_, v in sdl.items()}, input_ids=ids, labels=labels, attention_mask=am, images=images, images_dm=images_dm,
               loss=out.loss.detach(), logits=out.logits.detach(), lm_loss=out.additional_log_info["lm_loss"],
               vm_loss=out.additional_log_info["vm_loss"],
               grad_dream=lm.model.dream_embedding.dream_queries.grad.detach().clone(),
-              grad_embed=lm.model.embed_tokens.weight.grad.detach().clone(),
-              grad_lm_head=lm.lm_head.weight.grad.detach().clone(),
-              grad_q0=lm.model.layers[0].self_attn.q_proj.weight.grad.detach().clone(),
+              grad_embed=b16(lm.model.embed_tokens.weight.grad.detach().clone()),
+              grad_lm_head=b16(lm.lm_head.weight.grad.detach().clone()),
+              grad_q0=b16(lm.model.layers[0].self_attn.q_proj.weight.grad.detach().clone()),
+              grad_clip_proj=lm.model.clip_vision_embedding.proj.weight.grad.detach().clone(),
               loss_weight_lm=cfg.loss_weight_lm, loss_weight_vm=cfg.loss_weight_vm)
     # restatement check
     with torch.no_grad():
@@ -210,8 +221,11 @@ def main():
                                   model_name_or_path=None), 48, 64, bias=True)
     mlp = pb.build_projector(dict(projector="mlp", freeze_projector=False, depth=2, save_model_name="sd",
                                   model_name_or_path=None), 64, 32, bias=False)
-    xp = torch.randn(3, 7, 48)
-    xq = torch.randn(3, 7, 64)
+    init_params(lin)
+    init_params(mlp)
+    lin.projector.bias.data = bf16r(0.1 * torch.randn(64))
+    xp = bf16r(torch.randn(3, 7, 48))
+    xq = bf16r(torch.randn(3, 7, 64))
     yl = lin(xp)[-1].detach()
     ym = mlp(xq)[-1].detach()
     assert rel(llm_ref.linear_projector(xp, lin.projector.weight, lin.projector.bias), yl) < 1e-6
