@@ -24,9 +24,13 @@ SIGNATURES = {
     "dllm_layernorm_fwd": [c_void_p] * 6 + [c_i64, c_int, c_float, c_void_p],
     "dllm_layernorm_bwd": [c_void_p] * 10 + [c_int, c_i64, c_int, c_void_p],
     "dllm_gemm_bf16": [c_void_p] * 5 + [c_i64] * 7 + [c_int] * 5 + [c_float, c_void_p],
-    "dllm_conv2d_nhwc_bf16": [c_void_p] * 5 + [c_int] * 15 + [c_void_p],
+    "dllm_conv2d_nhwc_bf16": [c_void_p] * 6 + [c_int] * 15 + [c_void_p],
+    "dllm_groupnorm_fwd": [c_void_p] * 8 + [c_int] * 4 + [c_float, c_int, c_void_p],
+    "dllm_groupnorm_bwd": [c_void_p] * 10 + [c_int] * 5 + [c_void_p],
+    "dllm_sumpool2_nhwc": [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p],
+    "dllm_cfg_ddim_step": [c_void_p] * 3 + [c_i64, c_i64] + [c_float] * 5 + [c_int, c_void_p],
     "dllm_attn_fwd": [c_void_p] * 6 + [c_int] * 6 + [c_i64] * 9 + [c_float, c_int, c_void_p],
-    "dllm_attn_bwd": [c_void_p] * 11 + [c_int] * 6 + [c_i64] * 9 + [c_float, c_int, c_void_p],
+    "dllm_attn_bwd": [c_void_p] * 11 + [c_int] * 6 + [c_i64] * 15 + [c_float, c_int, c_void_p],
     "dllm_rope": [c_void_p] * 4 + [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void_p],
     "dllm_glu_fwd": [c_void_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_i64, c_int, c_void_p],
     "dllm_glu_bwd": [c_void_p] * 5 + [c_i64, c_int] + [c_i64] * 5 + [c_int, c_void_p],
@@ -45,6 +49,9 @@ SIGNATURES = {
     "dllm_probe_tr16": [c_void_p, c_void_p, c_void_p],
     "dllm_probe_mfma16": [c_void_p, c_void_p, c_void_p, c_void_p],
 }
+
+# functions whose return type is not int
+RESTYPES = {"dllm_groupnorm_ws_floats": (c_i64, [c_int, c_int, c_int])}
 
 _lib = None
 
@@ -69,6 +76,11 @@ def lib() -> ctypes.CDLL:
                 continue  # reported by tests/test_abi.py; calling it raises below
             fn.argtypes = argtypes
             fn.restype = c_int
+        for name, (rt, argtypes) in RESTYPES.items():
+            fn = getattr(_lib, name, None)
+            if fn is not None:
+                fn.argtypes = argtypes
+                fn.restype = rt
     return _lib
 
 

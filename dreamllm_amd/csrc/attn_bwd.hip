@@ -59,9 +59,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
     const int sk_len = P.seqlens ? min(P.seqlens[b], P.Sk) : P.Sk;
     const int q0 = qblk * BQ, wq0 = q0 + wave * (QT * 16);
     const int coff = sk_len - sq_len;
-    // dq is a dense [B,Sq,H,D] tensor
-    bf16* dqbase = P.dq + ((int64_t)b * P.Sq * P.H + h) * D;
-    const int64_t dq_ss = (int64_t)P.H * D;
+    bf16* dqbase = P.dq + (int64_t)b * P.dq_sb + (int64_t)h * P.dq_sh;
+    const int64_t dq_ss = P.dq_ss;
 
     if (q0 >= sq_len) {
         for (int i = tid; i < BQ * (D / 8); i += 256) {
@@ -221,9 +220,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
     const int sk_len = P.seqlens ? min(P.seqlens[b], P.Sk) : P.Sk;
     const int k0 = blockIdx.x * BKEYS, wk0 = k0 + wave * (KT * 16);
     const int coff = sk_len - sq_len;
-    bf16* dkbase = P.dk + ((int64_t)b * P.Sk * P.Hkv + hk) * D;
-    bf16* dvbase = P.dv + ((int64_t)b * P.Sk * P.Hkv + hk) * D;
-    const int64_t dk_ss = (int64_t)P.Hkv * D;
+    bf16* dkbase = P.dk + (int64_t)b * P.dk_sb + (int64_t)hk * P.dk_sh;
+    bf16* dvbase = P.dv + (int64_t)b * P.dk_sb + (int64_t)hk * P.dk_sh;
+    const int64_t dk_ss = P.dk_ss;
 
     // this wave's keys as B operands: lane = key t of tile kt, d = ds*32 + g*8 ..
     bf16x8 kfB[KT][DS], vfB[KT][DS];
@@ -399,16 +398,19 @@ int launch_bwd(const AttnParams& P, hipStream_t stream) {
 
 extern "C" {
 
-// dout/o share the o strides; q and k/v strides as in dllm_attn_fwd; dq [B,Sq,H,D], dk/dv [B,Sk,Hkv,D] dense outputs;
+// dout/o share the o strides; q and k/v strides as in dllm_attn_fwd; dq is a [B,Sq,H,D] view with strides dq_*, dk/dv are
+// [B,Sk,Hkv,D] views sharing strides dk_* (so gradients can be written straight into a packed dQKV buffer);
 // delta: fp32 [B,H,Sq] workspace.
 int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* o, const float* lse, float* delta,
                   void* dq, void* dk, void* dv, const int* seqlens, int B, int H, int Hkv, int Sq, int Sk, int D, int64_t q_sb,
                   int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
-                  float scale, int causal, void* stream) {
+                  int64_t dq_sb, int64_t dq_ss, int64_t dq_sh, int64_t dk_sb, int64_t dk_ss, int64_t dk_sh, float scale,
+                  int causal, void* stream) {
     if (B < 0 || H <= 0 || Hkv <= 0 || Sq < 0 || Sk < 0 || (H % Hkv) != 0) return DLLM_ERR_SHAPE;
     if (D != 64 && D != 128) return DLLM_ERR_SHAPE;
     if (B == 0 || Sq == 0 || Sk == 0) return DLLM_OK;
     if ((q_ss | q_sh | q_sb | k_ss | k_sh | k_sb | o_ss | o_sh | o_sb) & 7) return DLLM_ERR_ALIGN;
+    if ((dq_ss | dq_sh | dq_sb | dk_ss | dk_sh | dk_sb) & 3) return DLLM_ERR_ALIGN;
     if (seqlens != nullptr && Sq != Sk) return DLLM_ERR_SHAPE;
     if (lse == nullptr || delta == nullptr) return DLLM_ERR_SHAPE;
     AttnParams P{};
@@ -417,6 +419,7 @@ int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v,
     P.B = B; P.H = H; P.Hkv = Hkv; P.Sq = Sq; P.Sk = Sk;
     P.q_sb = q_sb; P.q_ss = q_ss; P.q_sh = q_sh; P.k_sb = k_sb; P.k_ss = k_ss; P.k_sh = k_sh;
     P.o_sb = o_sb; P.o_ss = o_ss; P.o_sh = o_sh; P.scale = scale; P.causal = causal;
+    P.dq_sb = dq_sb; P.dq_ss = dq_ss; P.dq_sh = dq_sh; P.dk_sb = dk_sb; P.dk_ss = dk_ss; P.dk_sh = dk_sh;
     hipStream_t s = (hipStream_t)stream;
     if (D == 128) return causal ? launch_bwd<128, true>(P, s) : launch_bwd<128, false>(P, s);
     return causal ? launch_bwd<64, true>(P, s) : launch_bwd<64, false>(P, s);

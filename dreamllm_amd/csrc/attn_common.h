@@ -111,6 +111,8 @@ struct AttnParams {
     int64_t q_sb, q_ss, q_sh;      // element strides of q / o / dout / dq
     int64_t k_sb, k_ss, k_sh;      // element strides of k / v / dk / dv
     int64_t o_sb, o_ss, o_sh;
+    int64_t dq_sb, dq_ss, dq_sh;   // element strides of dq
+    int64_t dk_sb, dk_ss, dk_sh;   // element strides of dk / dv
     float scale;
     int causal;
 };

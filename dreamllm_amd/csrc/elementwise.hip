@@ -262,6 +262,42 @@ __global__ __launch_bounds__(256) void mse_bwd_kernel(const bf16* __restrict__ a
         da[i] = (bf16)(((float)a[i] - b[i]) * gs);
 }
 
+// ------------------------------------------------------------------ fused classifier-free guidance + DDIM(eta=0) step
+// One thread per latent pixel (4 channels, NHWC).  Replaces modeling_plugins.py:824-833 (chunk, CFG combine,
+// scheduler.step) and the next iteration's torch.cat([latents]*2) + cast (:811-812):
+//   eps = e_u + s (e_c - e_u);  x0 = (x - sqrt(1-a_t) eps)/sqrt(a_t)  [epsilon]  or  sqrt(a_t) x - sqrt(1-a_t) v  [v-pred]
+//   x_prev = sqrt(a_prev) x0 + sqrt(1-a_prev) eps
+// pred: bf16 [2B][P][4] (uncond batch first), lat: fp32 [B][P][4] in/out, next_in: bf16 [2B][P][8] (channels 4..7 zero,
+// the conv_in operand of the next step) or null.
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const bf16* __restrict__ pred, float* __restrict__ lat,
+                                                       bf16* __restrict__ next_in, int64_t BP, int64_t total_half, float gs,
+                                                       float sa, float s1a, float sap, float s1ap, int vpred) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < BP; i += (int64_t)gridDim.x * 256) {
+        const bf16x4 eu = ld_bf16x4(pred + i * 4), ec = ld_bf16x4(pred + (total_half + i) * 4);
+        f32x4 x = *reinterpret_cast<f32x4*>(lat + i * 4);
+        bf16x8 o = zero_bf16x8();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float u = (float)eu[c];
+            float e = u + gs * ((float)ec[c] - u);
+            float x0;
+            if (vpred) {
+                x0 = sa * x[c] - s1a * e;
+                e = sa * e + s1a * x[c];
+            } else {
+                x0 = (x[c] - s1a * e) / sa;
+            }
+            x[c] = sap * x0 + s1ap * e;
+            o[c] = (bf16)x[c];
+        }
+        *reinterpret_cast<f32x4*>(lat + i * 4) = x;
+        if (next_in != nullptr) {
+            st_bf16x8(next_in + i * 8, o);
+            st_bf16x8(next_in + (total_half + i) * 8, o);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ add / broadcast add / stand-alone activations
 // out[i] = a[i] + b[i % period]  (period == n: plain add).  Used for residual adds outside a GEMM epilogue, the CLIP
 // position embedding and the per-(image,channel) time-embedding add of the UNet ResBlock (with row_period).
@@ -519,6 +555,17 @@ int dllm_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int mode, v
     if (mode == 1) hipLaunchKernelGGL(act_bwd_kernel<1>, dim3(g), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, n / 8);
     else if (mode == 2) hipLaunchKernelGGL(act_bwd_kernel<2>, dim3(g), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, n / 8);
     else hipLaunchKernelGGL(act_bwd_kernel<3>, dim3(g), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, (bf16*)dx, n / 8);
+    return dllm_check_launch();
+}
+
+// n_half = B * pixels (latent pixels of the conditional half); see cfg_ddim_kernel for layouts.
+int dllm_cfg_ddim_step(const void* pred, float* latents, void* next_in, int64_t n_half, int64_t unused, float guidance,
+                       float sqrt_at, float sqrt_1mat, float sqrt_aprev, float sqrt_1maprev, int v_prediction, void* stream) {
+    if (n_half < 0) return DLLM_ERR_SHAPE;
+    if (n_half == 0) return DLLM_OK;
+    (void)unused;
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n_half)), dim3(256), 0, (hipStream_t)stream, (const bf16*)pred, latents,
+                       (bf16*)next_in, n_half, n_half, guidance, sqrt_at, sqrt_1mat, sqrt_aprev, sqrt_1maprev, v_prediction);
     return dllm_check_launch();
 }
 

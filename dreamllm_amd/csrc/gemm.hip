@@ -45,6 +45,8 @@ struct GemmParams {
     void* C;
     const bf16* bias;      // [N] or null
     const bf16* residual;  // [M, ldr] or null (added after activation)
+    const bf16* rg_bias;   // [M / rg_rows, N] or null: per-row-group bias (UNet time embedding per image), before activation
+    int64_t rg_rows;
     int64_t M, N, K;
     int64_t lda, ldb, ldc, ldr;
     int epi;
@@ -299,6 +301,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams P) {
                 for (int r = 0; r < 4; ++r)
                     if (r < nvalid) v[r] += (float)P.bias[n + r];
             }
+            if (P.rg_bias != nullptr) {
+                const bf16* rb = P.rg_bias + (m / P.rg_rows) * P.N + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nvalid) v[r] += (float)rb[r];
+            }
             if (P.epi == EPI_GELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
@@ -401,9 +409,10 @@ int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, cons
 // x: [NB,H,W,C] bf16, w: [CO, KH*KW*C] bf16 (k-contiguous), out: [NB,OH,OW,CO].
 // up2: the logical input is the nearest-2x upsampling of x (Upsample2D + conv fused).
 // even_only: transposed gather used for the dgrad of a stride-2 conv (logical stride 1 over a zero-stuffed grid).
-int dllm_conv2d_nhwc_bf16(const void* x, const void* w, void* out, const void* bias, const void* residual, int NB, int H,
-                          int W, int C, int OH, int OW, int CO, int KH, int KW, int stride, int pad, int up2, int even_only,
-                          int epi, int out_dtype, void* stream) {
+// image_bias: optional bf16 [NB, CO] added per image (ResnetBlock2D time_emb_proj broadcast), before the activation.
+int dllm_conv2d_nhwc_bf16(const void* x, const void* w, void* out, const void* bias, const void* residual,
+                          const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
+                          int stride, int pad, int up2, int even_only, int epi, int out_dtype, void* stream) {
     if (NB < 0 || H <= 0 || W <= 0 || C <= 0 || CO <= 0 || OH <= 0 || OW <= 0) return DLLM_ERR_SHAPE;
     if (NB == 0) return DLLM_OK;
     if ((C & 7) != 0) return DLLM_ERR_ALIGN;
@@ -414,6 +423,7 @@ int dllm_conv2d_nhwc_bf16(const void* x, const void* w, void* out, const void* b
     P.M = (int64_t)NB * OH * OW; P.N = CO; P.K = (int64_t)KH * KW * C;
     P.lda = C; P.ldb = P.K; P.ldc = CO; P.ldr = CO;
     P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = 0; P.alpha = 1.0f;
+    P.rg_bias = (const bf16*)image_bias; P.rg_rows = (int64_t)OH * OW;
     P.cv = ConvGeom{H, W, C, OH, OW, KH, KW, stride, pad, up2, even_only};
     return launch_gemm<A_CONV, B_K>(P, (hipStream_t)stream);
 }

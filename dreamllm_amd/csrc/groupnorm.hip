@@ -1,0 +1,294 @@
+// GroupNorm (+ optional SiLU) on NHWC bf16 activations, forward and input-gradient (frozen affine), for the SD UNet:
+// ResnetBlock2D norm1/norm2 (+SiLU), Transformer2DModel.norm, conv_norm_out (+SiLU)  [diffusers 0.24, SURVEY.md A.1].
+//
+// NHWC keeps a pixel's C channels contiguous (the layout the implicit-GEMM conv and the attention token view want), so
+// a group's elements are strided: C/32 channels per pixel.  HBM-bound; three launches, all deterministic:
+//   1. partial per-channel sums over pixel chunks: thread owns a fixed 8-channel vector, 16-byte coalesced loads
+//   2. finalize: per (image, group) reduce chunks x channels -> per-channel affine  y = x*a + b   (a = rstd*gamma,
+//      b = beta - mean*rstd*gamma), stored as [N, C] fp32 (and mean/rstd for the backward)
+//   3. apply: y = silu?(x*a + b), 16-byte loads/stores.
+// Algorithmic traffic: 6 B/element forward (x read twice, y written once).
+// Backward (dx only): dz = dy*silu'(z); dxhat = dz*gamma; dx = rstd*(dxhat - mean_g(dxhat) - xhat*mean_g(dxhat*xhat)).
+#include "common.h"
+
+namespace {
+
+// grid (chunks, N); block = CV * R threads (CV = C/8 channel vectors, R rows in flight); x viewed [N][HW][C]
+// MODE 0: accumulate (x, x^2); MODE 1 (backward): accumulate (dxhat, dxhat*xhat) with xhat from ab_mean/rstd.
+template <int MODE>
+__global__ void gn_partial_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ mean,
+                                  const float* __restrict__ rstd, const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
+                                  float* __restrict__ part, int HW, int C, int G, int pix_per_chunk, int act) {
+    extern __shared__ float red[];  // [R][CV][16]
+    const int CV = C >> 3;
+    const int R = blockDim.x / CV;
+    const int cv = threadIdx.x % CV, r = threadIdx.x / CV;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * pix_per_chunk, p1 = min(HW, p0 + pix_per_chunk);
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    float mu[8], rs[8], ga[8], be[8];
+    if (MODE == 1) {
+        const int cpg = C / G;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cv * 8 + e;
+            mu[e] = mean[n * G + c / cpg];
+            rs[e] = rstd[n * G + c / cpg];
+            ga[e] = (float)gamma[c];
+            be[e] = (float)beta[c];
+        }
+    }
+    if (r < R) {
+        for (int p = p0 + r; p < p1; p += R) {
+            const int64_t off = ((int64_t)n * HW + p) * C + cv * 8;
+            const bf16x8 v = ld_bf16x8(x + off);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float f = (float)v[e];
+                    s1[e] += f;
+                    s2[e] += f * f;
+                }
+            } else {
+                const bf16x8 d = ld_bf16x8(dy + off);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = ((float)v[e] - mu[e]) * rs[e];
+                    float dz = (float)d[e];
+                    if (act) {
+                        const float z = xh * ga[e] + be[e];
+                        const float sg = sigmoid_f(z);
+                        dz *= sg * (1.f + z * (1.f - sg));
+                    }
+                    const float dxh = dz * ga[e];
+                    s1[e] += dxh;
+                    s2[e] += dxh * xh;
+                }
+            }
+        }
+    }
+    float* my = red + ((size_t)r * CV + cv) * 16;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        my[e] = s1[e];
+        my[8 + e] = s2[e];
+    }
+    __syncthreads();
+    if (r == 0) {
+        for (int rr = 1; rr < R; ++rr) {
+            const float* o = red + ((size_t)rr * CV + cv) * 16;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                s1[e] += o[e];
+                s2[e] += o[8 + e];
+            }
+        }
+        float* dst = part + (((int64_t)n * gridDim.x + chunk) * C + cv * 8) * 2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dst[e * 2] = s1[e];
+            dst[e * 2 + 1] = s2[e];
+        }
+    }
+}
+
+// one block (64 threads) per (n, g): reduce part[n][chunk][c][2] over chunks and the group's channels.
+// MODE 0: -> mean, rstd, and per-channel a/b.  MODE 1: -> c1 = mean_g(dxhat), c2 = mean_g(dxhat*xhat) into out1/out2.
+template <int MODE>
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, const bf16* __restrict__ gamma,
+                                                         const bf16* __restrict__ beta, float* __restrict__ out1,
+                                                         float* __restrict__ out2, float* __restrict__ ab, int nchunks, int HW,
+                                                         int C, int G, float eps) {
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int cpg = C / G;
+    float s1 = 0.f, s2 = 0.f;
+    const int items = nchunks * cpg;
+    for (int i = threadIdx.x; i < items; i += 64) {
+        const int ch = i / cpg, c = g * cpg + i % cpg;
+        const float* p = part + (((int64_t)n * nchunks + ch) * C + c) * 2;
+        s1 += p[0];
+        s2 += p[1];
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float cnt = (float)HW * (float)cpg;
+    if (MODE == 0) {
+        const float mean = s1 / cnt;
+        const float var = fmaxf(s2 / cnt - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + eps);
+        if (threadIdx.x == 0) {
+            out1[n * G + g] = mean;
+            out2[n * G + g] = rstd;
+        }
+        for (int i = threadIdx.x; i < cpg; i += 64) {
+            const int c = g * cpg + i;
+            const float a = rstd * (float)gamma[c];
+            ab[((int64_t)n * C + c) * 2] = a;
+            ab[((int64_t)n * C + c) * 2 + 1] = (float)beta[c] - mean * a;
+        }
+    } else if (threadIdx.x == 0) {
+        out1[n * G + g] = s1 / cnt;
+        out2[n * G + g] = s2 / cnt;
+    }
+}
+
+// y = act(x * a[n,c] + b[n,c])
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ x, const float* __restrict__ ab,
+                                                       bf16* __restrict__ y, int64_t total_vec, int HW, int C, int act) {
+    const int CV = C >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        const int64_t n = i / ((int64_t)CV * HW);
+        const bf16x8 v = ld_bf16x8(x + i * 8);
+        const float* p = ab + (n * C + cv * 8) * 2;
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float z = (float)v[e] * p[e * 2] + p[e * 2 + 1];
+            if (act) z = silu_f(z);
+            o[e] = (bf16)z;
+        }
+        st_bf16x8(y + i * 8, o);
+    }
+}
+
+// dx = rstd * (dxhat - c1 - xhat * c2)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ c1, const float* __restrict__ c2,
+                                                           const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
+                                                           bf16* __restrict__ dx, int64_t total_vec, int HW, int C, int G,
+                                                           int act) {
+    const int CV = C >> 3, cpg = C / G;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        const int n = (int)(i / ((int64_t)CV * HW));
+        const bf16x8 v = ld_bf16x8(x + i * 8), d = ld_bf16x8(dy + i * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cv * 8 + e;
+            const int ng = n * G + c / cpg;
+            const float rs = rstd[ng];
+            const float xh = ((float)v[e] - mean[ng]) * rs;
+            const float ga = (float)gamma[c];
+            float dz = (float)d[e];
+            if (act) {
+                const float z = xh * ga + (float)beta[c];
+                const float sg = sigmoid_f(z);
+                dz *= sg * (1.f + z * (1.f - sg));
+            }
+            o[e] = (bf16)(rs * (dz * ga - c1[ng] - xh * c2[ng]));
+        }
+        st_bf16x8(dx + i * 8, o);
+    }
+}
+
+// 2x2 sum pooling on NHWC: backward of nearest-2x upsampling.  in [N,2H,2W,C] -> out [N,H,W,C]
+__global__ __launch_bounds__(256) void sumpool2_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int64_t total_vec,
+                                                       int H, int W, int C) {
+    const int CV = C >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+        const int cv = (int)(i % CV);
+        int64_t t = i / CV;
+        const int w = (int)(t % W);
+        t /= W;
+        const int h = (int)(t % H);
+        const int64_t n = t / H;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                const bf16x8 v = ld_bf16x8(in + (((n * 2 * H + 2 * h + dh) * 2 * W) + 2 * w + dw) * C + cv * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+        st_bf16x8(out + i * 8, o);
+    }
+}
+
+inline int gn_geometry(int HW, int C, int NB, int* block, int* nchunks, int* ppc) {
+    if (C % 8 != 0) return -1;
+    const int CV = C / 8;
+    if (CV > 1024) return -1;
+    int R = CV <= 256 ? 256 / CV : 1;
+    *block = CV * R;
+    // aim for >= 1024 blocks overall, chunks of >= 16 pixels
+    int chunks = (1024 + NB - 1) / NB;
+    int p = (HW + chunks - 1) / chunks;
+    if (p < 16) p = 16;
+    *ppc = p;
+    *nchunks = (HW + p - 1) / p;
+    return R;
+}
+
+}  // namespace
+
+extern "C" {
+
+// workspace sizes (floats): partials = N * nchunks * C * 2
+int64_t dllm_groupnorm_ws_floats(int NB, int HW, int C) {
+    int block, nchunks, ppc;
+    if (gn_geometry(HW, C, NB, &block, &nchunks, &ppc) < 0) return -1;
+    return (int64_t)NB * nchunks * C * 2;
+}
+
+// x,y: [NB, HW, C] bf16 (NHWC); mean,rstd: fp32 [NB, G] outputs (kept for backward); ab: fp32 [NB, C, 2] scratch;
+// part: fp32 scratch of dllm_groupnorm_ws_floats().  act: 0 none, 1 SiLU.
+int dllm_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, float* ab,
+                       float* part, int NB, int HW, int C, int G, float eps, int act, void* stream) {
+    if (NB < 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) != 0) return DLLM_ERR_SHAPE;
+    if (NB == 0) return DLLM_OK;
+    int block, nchunks, ppc;
+    const int R = gn_geometry(HW, C, NB, &block, &nchunks, &ppc);
+    if (R < 0) return DLLM_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)block * 16 * sizeof(float);
+    hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunks, NB), dim3(block), lds, s, (const bf16*)x, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, part, HW, C, G, ppc, 0);
+    hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3(NB * G), dim3(64), 0, s, part, (const bf16*)gamma, (const bf16*)beta, mean,
+                       rstd, ab, nchunks, HW, C, G, eps);
+    const int64_t tv = (int64_t)NB * HW * (C / 8);
+    int grid = (int)((tv + 255) / 256 > 8192 ? 8192 : (tv + 255) / 256);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, ab, (bf16*)y, tv, HW, C, act);
+    return dllm_check_launch();
+}
+
+// dx only (affine parameters frozen).  c1,c2: fp32 [NB, G] scratch.
+int dllm_groupnorm_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean, const float* rstd,
+                       void* dx, float* c1, float* c2, float* part, int NB, int HW, int C, int G, int act, void* stream) {
+    if (NB < 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) != 0) return DLLM_ERR_SHAPE;
+    if (NB == 0) return DLLM_OK;
+    int block, nchunks, ppc;
+    const int R = gn_geometry(HW, C, NB, &block, &nchunks, &ppc);
+    if (R < 0) return DLLM_ERR_SHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)block * 16 * sizeof(float);
+    hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunks, NB), dim3(block), lds, s, (const bf16*)x, (const bf16*)dy, mean, rstd,
+                       (const bf16*)gamma, (const bf16*)beta, part, HW, C, G, ppc, act);
+    hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(NB * G), dim3(64), 0, s, part, nullptr, nullptr, c1, c2, nullptr, nchunks, HW,
+                       C, G, 0.f);
+    const int64_t tv = (int64_t)NB * HW * (C / 8);
+    int grid = (int)((tv + 255) / 256 > 8192 ? 8192 : (tv + 255) / 256);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, mean, rstd, c1, c2,
+                       (const bf16*)gamma, (const bf16*)beta, (bf16*)dx, tv, HW, C, G, act);
+    return dllm_check_launch();
+}
+
+// in [NB, 2H, 2W, C] -> out [NB, H, W, C] (sum of each 2x2 window)
+int dllm_sumpool2_nhwc(const void* in, void* out, int NB, int H, int W, int C, void* stream) {
+    if (NB < 0 || H <= 0 || W <= 0 || C <= 0 || (C & 7)) return DLLM_ERR_SHAPE;
+    if (NB == 0) return DLLM_OK;
+    const int64_t tv = (int64_t)NB * H * W * (C / 8);
+    int grid = (int)((tv + 255) / 256 > 8192 ? 8192 : (tv + 255) / 256);
+    hipLaunchKernelGGL(sumpool2_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16*)in, (bf16*)out, tv, H, W, C);
+    return dllm_check_launch();
+}
+
+}  // extern "C"

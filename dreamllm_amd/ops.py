@@ -206,7 +206,9 @@ def attn_fwd(q, k, v, causal, scale=None, seqlens=None, need_lse=True):
     return o, lse
 
 
-def attn_bwd(dout, q, k, v, o, lse, causal, scale=None, seqlens=None):
+def attn_bwd(dout, q, k, v, o, lse, causal, scale=None, seqlens=None, dq=None, dk=None, dv=None):
+    """-> dq [B,Sq,H,D], dk/dv [B,Sk,Hkv,D].  dq/dk/dv may be preallocated (strided) views, e.g. slices of one packed
+    dQKV buffer; dk and dv must share strides."""
     B, Sq, H, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
     scale = scale if scale is not None else 1.0 / math.sqrt(D)
@@ -215,13 +217,18 @@ def attn_bwd(dout, q, k, v, o, lse, causal, scale=None, seqlens=None):
     dout = dout if (dout.stride(-1) == 1 and dout.stride() == o.stride()) else dout.contiguous()
     if dout.stride() != o.stride():
         o = o.contiguous()
-    dq = torch.empty(B, Sq, H, D, dtype=q.dtype, device=q.device)
-    dk = torch.empty(B, Sk, Hkv, D, dtype=q.dtype, device=q.device)
-    dv = torch.empty(B, Sk, Hkv, D, dtype=q.dtype, device=q.device)
+    if dq is None:
+        dq = torch.empty(B, Sq, H, D, dtype=q.dtype, device=q.device)
+    if dk is None:
+        dk = torch.empty(B, Sk, Hkv, D, dtype=q.dtype, device=q.device)
+        dv = torch.empty(B, Sk, Hkv, D, dtype=q.dtype, device=q.device)
+    if dk.stride() != dv.stride():
+        raise ValueError("dk and dv must share strides")
     delta = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
     check("dllm_attn_bwd", _p(dout), _p(q), _p(k), _p(v), _p(o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(seqlens),
           B, H, Hkv, Sq, Sk, D, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
-          o.stride(0), o.stride(1), o.stride(2), float(scale), int(causal), _stream())
+          o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1),
+          dk.stride(2), float(scale), int(causal), _stream())
     return dq, dk, dv
 
 
@@ -680,3 +687,265 @@ class LMHeadCEFn(torch.autograd.Function):
 
 def lm_head_ce(hidden2d, weight, labels1d):
     return LMHeadCEFn.apply(hidden2d, weight, labels1d)
+
+
+# --------------------------------------------------------------------------------------------- UNet operators (NHWC)
+def conv2d_nhwc(x, w2d, CO, KH, KW, stride=1, pad=1, OH=None, OW=None, bias=None, residual=None, image_bias=None, up2=False,
+                even_only=False, epi=None, out_dtype=torch.bfloat16):
+    """x [N,H,W,C] bf16 (C % 8 == 0), w2d [CO, KH*KW*C] k-contiguous -> [N,OH,OW,CO].  Implicit-GEMM MFMA kernel."""
+    _need_gpu(x, w2d, bias, residual, image_bias)
+    _bf16(x, w2d, bias, residual, image_bias)
+    x = x if x.is_contiguous() else x.contiguous()
+    N, H, W, C = x.shape
+    if OH is None:
+        Hl, Wl = (2 * H, 2 * W) if up2 else (H, W)
+        OH = (Hl + 2 * pad - KH) // stride + 1
+        OW = (Wl + 2 * pad - KW) // stride + 1
+    out = torch.empty(N, OH, OW, CO, dtype=out_dtype, device=x.device)
+    if residual is not None and not residual.is_contiguous():
+        residual = residual.contiguous()
+    check("dllm_conv2d_nhwc_bf16", _p(x), _p(w2d), _p(out), _p(bias), _p(residual), _p(image_bias), N, H, W, C, OH, OW, CO,
+          KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), _stream())
+    return out
+
+
+def sumpool2(x):
+    """[N,2H,2W,C] -> [N,H,W,C]: backward of nearest-2x upsampling."""
+    N, H2, W2, C = x.shape
+    x = x.contiguous()
+    out = torch.empty(N, H2 // 2, W2 // 2, C, dtype=x.dtype, device=x.device)
+    check("dllm_sumpool2_nhwc", _p(x), _p(out), N, H2 // 2, W2 // 2, C, _stream())
+    return out
+
+
+class ConvFn(torch.autograd.Function):
+    """Conv2d on NHWC with FROZEN weights: forward + input gradient only (the UNet/VAE are frozen in every dreamllm recipe,
+    modeling_plugins.py:405-407).  mode: "same" (stride 1), "down" (stride 2), "up" (nearest-2x upsample fused in front)."""
+
+    @staticmethod
+    def forward(ctx, x, w_fwd, w_bwd, bias, residual, image_bias, CO, K, mode):
+        pad = 1 if K == 3 else 0
+        if mode == "down_asym":  # VAE encoder Downsample2D: F.pad(x, (0,1,0,1)) then stride-2 conv with padding 0
+            y = conv2d_nhwc(x, w_fwd, CO, K, K, stride=2, pad=0, OH=x.shape[1] // 2, OW=x.shape[2] // 2, bias=bias)
+        else:
+            y = conv2d_nhwc(x, w_fwd, CO, K, K, stride=2 if mode == "down" else 1, pad=pad, bias=bias, residual=residual,
+                            image_bias=image_bias, up2=(mode == "up"))
+        ctx.save_for_backward(w_bwd)
+        ctx.meta = (x.shape, K, mode, residual is not None, image_bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (w_bwd,) = ctx.saved_tensors
+        xshape, K, mode, has_res, has_ib = ctx.meta
+        dy = dy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            N, H, W, C = xshape
+            pad = 1 if K == 3 else 0
+            if dy.shape[-1] % 8 != 0:  # conv_out: 4 output channels -> pad the gradient's channels for 16-byte rows
+                dyp = torch.zeros(*dy.shape[:-1], (dy.shape[-1] + 7) // 8 * 8, dtype=dy.dtype, device=dy.device)
+                dyp[..., : dy.shape[-1]] = dy
+            else:
+                dyp = dy
+            Cw = w_bwd.shape[0]
+            if mode == "same":
+                dx = conv2d_nhwc(dyp, w_bwd, Cw, K, K, 1, pad)
+            elif mode == "down":
+                dx = conv2d_nhwc(dyp, w_bwd, Cw, K, K, 1, pad, OH=H, OW=W, even_only=True)
+            else:  # up: gradient w.r.t. the upsampled image, then fold the 2x2 replicas
+                dx = sumpool2(conv2d_nhwc(dyp, w_bwd, Cw, K, K, 1, pad))
+            if Cw != C:  # channel-padded input (conv_in)
+                dx = torch.nn.functional.pad(dx, (0, C - Cw))
+        dres = dy if (has_res and ctx.needs_input_grad[4]) else None
+        dib = None
+        if has_ib and ctx.needs_input_grad[5]:
+            dib = dy.reshape(dy.shape[0], -1, dy.shape[-1]).sum(1, dtype=torch.float32).to(dy.dtype)
+        return dx, None, None, None, dres, dib, None, None, None
+
+
+def groupnorm_fwd(x, gamma, beta, G, eps, act):
+    _need_gpu(x, gamma, beta)
+    _bf16(x, gamma, beta)
+    x = x if x.is_contiguous() else x.contiguous()
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    ws = _lib.lib().dllm_groupnorm_ws_floats(N, HW, C)
+    if ws < 0:
+        raise ValueError("groupnorm: unsupported shape")
+    part = torch.empty(ws, dtype=torch.float32, device=x.device)
+    mean = torch.empty(N, G, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(N, G, dtype=torch.float32, device=x.device)
+    ab = torch.empty(N, C, 2, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    check("dllm_groupnorm_fwd", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(ab), _p(part), N, HW, C, G, float(eps),
+          int(act), _stream())
+    return y, mean, rstd
+
+
+def groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act):
+    dy = dy.contiguous()
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (N * C)
+    ws = _lib.lib().dllm_groupnorm_ws_floats(N, HW, C)
+    part = torch.empty(ws, dtype=torch.float32, device=x.device)
+    c1 = torch.empty(N, G, dtype=torch.float32, device=x.device)
+    c2 = torch.empty(N, G, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    check("dllm_groupnorm_bwd", _p(dy), _p(x), _p(gamma), _p(beta), _p(mean), _p(rstd), _p(dx), _p(c1), _p(c2), _p(part), N, HW,
+          C, G, int(act), _stream())
+    return dx
+
+
+class GroupNormFn(torch.autograd.Function):
+    """GroupNorm(+SiLU) on NHWC, frozen affine: forward + input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, act):
+        x = x.contiguous()
+        y, mean, rstd = groupnorm_fwd(x, gamma, beta, G, eps, act)
+        if x.requires_grad:
+            ctx.save_for_backward(x, gamma, beta, mean, rstd)
+            ctx.meta = (G, act)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        G, act = ctx.meta
+        return groupnorm_bwd(dy, x, gamma, beta, mean, rstd, G, act), None, None, None, None, None
+
+
+def groupnorm(x, gamma, beta, G, eps, act=False):
+    return GroupNormFn.apply(x, gamma, beta, G, eps, act)
+
+
+class MSELossFn(torch.autograd.Function):
+    """F.mse_loss(pred.float(), target.float(), reduction='mean') (modeling_plugins.py:559) with pred bf16, target fp32."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred = pred.contiguous()
+        target = target.contiguous()
+        acc = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        check("dllm_mse_sum", _p(pred), _p(target), pred.numel(), _p(acc), _stream())
+        ctx.save_for_backward(pred, target)
+        return (acc / pred.numel()).reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        pred, target = ctx.saved_tensors
+        gs = dloss.to(torch.float32).reshape(1).contiguous()
+        dp = torch.empty_like(pred)
+        check("dllm_mse_bwd", _p(pred), _p(target), pred.numel(), _p(gs), _p(dp), _stream())
+        return dp, None
+
+
+def mse_loss(pred, target):
+    _need_gpu(pred, target)
+    _bf16(pred)
+    if target.dtype != torch.float32:
+        target = target.float()
+    return MSELossFn.apply(pred, target)
+
+
+def mse_loss_per_sample(pred, target):
+    """per-sample mean squared error (min-SNR weighting path, modeling_plugins.py:569-571)."""
+    return torch.stack([mse_loss(pred[i], target[i]) for i in range(pred.shape[0])])
+
+
+def cfg_ddim_step_(pred, latents, next_in, guidance, a_t, a_prev, v_prediction=False):
+    """Fused CFG combine + DDIM(eta=0) update (+ next UNet input).  pred bf16 [2B,P,4] NHWC, latents fp32 [B,P,4] in place,
+    next_in bf16 [2B,P,8] or None."""
+    _need_gpu(pred, latents, next_in)
+    n_half = latents.numel() // 4
+    check("dllm_cfg_ddim_step", _p(pred), _p(latents), _p(next_in), n_half, 0, float(guidance), float(a_t) ** 0.5,
+          float(1 - a_t) ** 0.5, float(a_prev) ** 0.5, float(1 - a_prev) ** 0.5, int(v_prediction), _stream())
+    return latents
+
+
+class PackedAttnFn(torch.autograd.Function):
+    """Self-attention on a packed [B,S,3,H,D] QKV GEMM output; the backward writes dQ/dK/dV straight into one packed
+    buffer (no zero-filled slice gradients)."""
+
+    @staticmethod
+    def forward(ctx, qkv, causal, scale):
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        o, lse = attn_fwd(q, k, v, causal, scale, None, need_lse=qkv.requires_grad)
+        if qkv.requires_grad:
+            ctx.save_for_backward(qkv, o, lse)
+        ctx.meta = (causal, scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, o, lse = ctx.saved_tensors
+        causal, scale = ctx.meta
+        dqkv = torch.empty_like(qkv)
+        attn_bwd(dout, qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, lse, causal, scale, None, dq=dqkv[:, :, 0],
+                 dk=dqkv[:, :, 1], dv=dqkv[:, :, 2])
+        return dqkv, None, None
+
+
+def packed_self_attn(qkv, causal=False, scale=None):
+    return PackedAttnFn.apply(qkv, causal, scale)
+
+
+class PackedKVAttnFn(torch.autograd.Function):
+    """Cross-attention: q [B,Sq,H,D] and a packed [B,Sk,2,H,D] K/V GEMM output."""
+
+    @staticmethod
+    def forward(ctx, q, kv, scale):
+        need = q.requires_grad or kv.requires_grad
+        o, lse = attn_fwd(q, kv[:, :, 0], kv[:, :, 1], False, scale, None, need_lse=need)
+        if need:
+            ctx.save_for_backward(q, kv, o, lse)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, o, lse = ctx.saved_tensors
+        dkv = torch.empty_like(kv)
+        dq, _, _ = attn_bwd(dout, q, kv[:, :, 0], kv[:, :, 1], o, lse, False, ctx.scale, None, dk=dkv[:, :, 0], dv=dkv[:, :, 1])
+        return dq, dkv, None
+
+
+def packed_cross_attn(q, kv, scale=None):
+    return PackedKVAttnFn.apply(q, kv, scale)
+
+
+class PackedGLUFn(torch.autograd.Function):
+    """GLU over ONE GEMM output h = [first | second] (last dim 2F).  mode 0: silu(first) * second (SwiGLU with
+    [gate | up]); mode 1: first * gelu(second) (diffusers GEGLU: hidden, gate = chunk(2)).  The backward writes both
+    halves of dh in place."""
+
+    @staticmethod
+    def forward(ctx, h, mode):
+        F_ = h.shape[-1] // 2
+        h2 = h.reshape(-1, 2 * F_)
+        a, b = (h2[:, :F_], h2[:, F_:]) if mode == 0 else (h2[:, F_:], h2[:, :F_])
+        ctx.save_for_backward(h)
+        ctx.mode = mode
+        return glu_fwd(a, b, mode).view(*h.shape[:-1], F_)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (h,) = ctx.saved_tensors
+        mode = ctx.mode
+        F_ = h.shape[-1] // 2
+        h2 = h.reshape(-1, 2 * F_)
+        dh = torch.empty_like(h2)
+        if mode == 0:
+            glu_bwd(dout, h2[:, :F_], h2[:, F_:], 0, da=dh[:, :F_], db=dh[:, F_:])
+        else:
+            glu_bwd(dout, h2[:, F_:], h2[:, :F_], 1, da=dh[:, F_:], db=dh[:, :F_])
+        return dh.view(h.shape), None
+
+
+def geglu_packed(h):
+    return PackedGLUFn.apply(h, 1)
+
+
+def swiglu_packed(h):
+    return PackedGLUFn.apply(h, 0)
