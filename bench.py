@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""Headline benchmark of the DreamLLM hot path on MI355X (contract: see the round brief; BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+One "step" = one stage-II interleaved training step on a synthetic batch already resident in HBM: DreamLLM-7B
+(Vicuna-7B dims, 32008 vocab) forward over B=16 x S=2048 interleaved documents with 2 comprehension + 2 creation images per
+document -> CLIP-ViT-L/14 encode -> multimodal splice -> 32 decoder layers -> dream-state gather -> SD-2.1 head (VAE encode,
+add_noise, UNet forward) -> lm_head + CE -> loss = 10*vm + 1*lm -> backward (LLM dgrad+wgrad, UNet dgrad) -> [RCCL gradient
+all-reduce through DDP when N > 1] -> global-norm clip + AdamW.  Nothing is skipped inside the timed region.
+
+value = whole-job training samples (sequences)/s = N*16*K / max-over-ranks wall time.  Weak scaling (16 seq/GPU).
+Also reported in the same JSON line (not part of `value`): SD-2.1 512 px denoise steps/s (50 deterministic DDIM steps,
+CFG 7.5 => UNet batch 2*B_img per step), `roofline` for the dominant kernel (the bf16 MFMA GEMM family, timed per launch
+with HIP events on the launch stream), `cpu_baseline` (oracle decoder layer fwd+bwd on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+# analytic algorithmic FLOPs (multiply-add = 2), SURVEY.md §8(d)
+FLOPS_TRAIN_SAMPLE = 88.1e12
+FLOPS_UNET_FWD = 0.803e12
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="sequences per GPU (projects/dreamllm/configs/stage2/base.py:78)")
+    ap.add_argument("--seq-len", type=int, default=2048)
+    ap.add_argument("--images-per-sample", type=int, default=2)
+    ap.add_argument("--model", default="7b", choices=["7b", "tiny"])
+    ap.add_argument("--denoise-batch", type=int, default=1)
+    ap.add_argument("--denoise-steps", type=int, default=50)
+    ap.add_argument("--no-denoise", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(seq_len):
+    """Oracle (`oracle/llm_ref.py`, kind "port") timed on the host cores: one Vicuna-7B decoder layer forward+backward at
+    B=1, fp32, scaled by the 32 layers + lm_head/CE to a full-model sample.  Bounded to a few tens of seconds."""
+    from oracle import llm_ref
+    torch.manual_seed(0)
+    H, Fd, nh = 4096, 11008, 32
+    S = min(seq_len, 1024)  # bounded sample: 1024 tokens of one sequence
+    sd = {}
+    for n, shp in (("self_attn.q_proj.weight", (H, H)), ("self_attn.k_proj.weight", (H, H)), ("self_attn.v_proj.weight", (H, H)),
+                   ("self_attn.o_proj.weight", (H, H)), ("mlp.gate_proj.weight", (Fd, H)), ("mlp.up_proj.weight", (Fd, H)),
+                   ("mlp.down_proj.weight", (H, Fd))):
+        sd[n] = (torch.randn(shp) * 0.02).requires_grad_(True)
+    sd["input_layernorm.weight"] = torch.ones(H, requires_grad=True)
+    sd["post_attention_layernorm.weight"] = torch.ones(H, requires_grad=True)
+    cfg = dict(num_attention_heads=nh, num_key_value_heads=nh, rms_norm_eps=1e-6)
+    cos, sin = llm_ref.rope_tables(H // nh, S)
+    x = torch.randn(1, S, H, requires_grad=True)
+    mask = llm_ref.causal_mask_4d(None, 1, S, torch.float32)
+    pos = torch.arange(S)[None]
+
+    def one():
+        y = llm_ref.decoder_layer(x, sd, "", cfg, cos, sin, pos, mask)
+        y.square().mean().backward()
+
+    one()  # warm-up
+    t0 = time.perf_counter()
+    one()
+    t_layer = time.perf_counter() - t0
+    # lm_head + CE forward/backward on the same tokens
+    w = (torch.randn(32008, H) * 0.02).requires_grad_(True)
+    h = torch.randn(S, H, requires_grad=True)
+    lab = torch.randint(0, 32008, (S,))
+    t0 = time.perf_counter()
+    torch.nn.functional.cross_entropy((h @ w.t()).float(), lab).backward()
+    t_head = time.perf_counter() - t0
+    tokens_per_s = S / (32 * t_layer + t_head)
+    return dict(value=tokens_per_s / seq_len, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/llm_ref decoder layer fwd+bwd, fp32, B=1 S={S} (x32 layers) + lm_head/CE; CLIP/UNet/VAE share "
+                       f"(4% of FLOPs) not included; host has {os.cpu_count()} logical cores")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from dreamllm_amd import distributed as D, ops
+    from dreamllm_amd.factory import TINY, VICUNA_7B, build_dreamllm
+    from dreamllm_amd.optim import HipAdamW
+    from dreamllm_amd.schedulers import DDIMScheduler
+    from dreamllm_amd.synthetic import make_interleaved_batch
+
+    D.init_distributed("nccl")
+    tiny = a.model == "tiny"
+    if tiny:
+        from oracle import unet_ref
+        model = build_dreamllm(TINY, device=dev, clip=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3,
+                                                           num_attention_heads=2, image_size=56),
+                               diffusion=dict(unet=unet_ref.tiny_config(64), vae=dict(block_out_channels=(32, 64, 64, 64),
+                                                                                      layers_per_block=1)),
+                               num_dream_queries=8)
+    else:
+        model = build_dreamllm(VICUNA_7B, device=dev)
+    head = model.stable_diffusion_head
+    result = {}
+
+    # ------------------------------------------------------------------ M2: SD-2.1 512 px denoise steps/s (replicas)
+    denoise = None
+    if not a.no_denoise:
+        Bi = a.denoise_batch
+        nq = model.model.dream_embedding.embed_len
+        g = torch.Generator().manual_seed(42)
+        pe = (torch.randn(Bi, nq, model.config.hidden_size, generator=g) * 0.02).to(dev, torch.bfloat16)
+        ne = (torch.randn(Bi, nq, model.config.hidden_size, generator=g) * 0.02).to(dev, torch.bfloat16)
+        sched = DDIMScheduler()
+        kw = dict(num_inference_steps=a.denoise_steps, guidance_scale=7.5, prompt_embeds=pe, negative_prompt_embeds=ne,
+                  output_type="latent", scheduler=sched)
+        if tiny:
+            kw.update(height=128, width=128)
+        head.pipeline(generator=torch.Generator().manual_seed(42), **{**kw, "num_inference_steps": 2})  # warm-up
+        D.synchronize()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        head.pipeline(generator=torch.Generator().manual_seed(42), **kw)
+        torch.cuda.synchronize()
+        dt = D.max_over_ranks(time.perf_counter() - t0)
+        sps = world * a.denoise_steps / dt
+        denoise = dict(metric="SD-2.1 512px denoise steps/s (50 DDIM eta=0, CFG 7.5, replicas)", value=round(sps, 3),
+                       unit="steps/s", batch_images=Bi, unet_batch=2 * Bi, ms_per_step=round(1e3 * dt / a.denoise_steps, 3),
+                       frac_mfma_peak=None if tiny else round(sps / world * 2 * Bi * FLOPS_UNET_FWD / (PEAK_BF16_TFLOPS * 1e12), 4))
+
+    # ------------------------------------------------------------------ M1: interleaved train samples/s
+    train = {}
+    if not a.no_train:
+        model.train()
+        ddp = D.wrap_ddp(model)
+        params = [p for p in model.parameters() if p.requires_grad]
+        opt = HipAdamW(params, lr=2e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
+        if tiny:
+            batch = make_interleaved_batch(a.batch, 512, 1, n_dream=8, n_patch=16, seed=1234 + rank, device=dev, image_size=56,
+                                           dm_size=128)
+        else:
+            batch = make_interleaved_batch(a.batch, a.seq_len, a.images_per_sample, seed=1234 + rank, device=dev)
+
+        def step():
+            out = ddp(**batch, return_dict=True)
+            out.loss.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return out
+
+        for _ in range(a.warmup):
+            out = step()
+        D.synchronize()
+        torch.cuda.synchronize()
+        ops.GEMM_PROFILE = []
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = step()
+        torch.cuda.synchronize()
+        D.synchronize()
+        dt = D.max_over_ranks(time.perf_counter() - t0)
+        prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+        loss_val = float(out.loss.item())
+        gsum = sum(f for _, _, f, _ in prof)
+        tsum = sum(s.elapsed_time(e) for s, e, _, _ in prof) * 1e-3
+        by_tag = {}
+        for s, e, f, tag in prof:
+            d = by_tag.setdefault(tag, [0.0, 0.0, 0])
+            d[0] += f
+            d[1] += s.elapsed_time(e) * 1e-3
+            d[2] += 1
+        samples = world * a.batch * a.steps
+        value = samples / dt
+        achieved = gsum / tsum / 1e12 if tsum > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get("gemm_bf16_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        train = dict(
+            value=value, ms_per_step=1e3 * dt / a.steps, loss=loss_val,
+            roofline=dict(bound="mfma", kernel="gemm_bf16_kernel (linear fwd/dgrad/wgrad + implicit-GEMM conv)",
+                          achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
+                          traffic=traffic, launches_per_step=len(prof) // max(a.steps, 1),
+                          avg_launch_ms=round(1e3 * tsum / max(len(prof), 1), 4),
+                          time_share_of_step=round(tsum / dt, 4),
+                          by_kind={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), launches=v[2] // max(a.steps, 1))
+                                   for k, v in by_tag.items() if v[1] > 0}),
+            e2e_frac_mfma_peak=None if tiny else round(value / world * FLOPS_TRAIN_SAMPLE / (PEAK_BF16_TFLOPS * 1e12), 4),
+        )
+
+    if rank == 0:
+        line = {
+            "metric": "interleaved train samples/sec (DreamLLM-7B stage-II fwd+bwd+allreduce+AdamW)",
+            "value": round(train.get("value", 0.0), 4), "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(train.get("ms_per_step", 0.0), 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": ("tiny smoke config" if tiny else
+                                    "DreamLLM-7B (Vicuna-7B + CLIP-ViT-L/14 + SD-2.1 UNet/VAE) stage-II interleaved-doc training step, "
+                                    "random-init weights"),
+                       "model": "dreamllm-7b" if not tiny else "tiny", "global_batch": world * a.batch, "per_gpu_batch": a.batch,
+                       "seq_len": a.seq_len if not tiny else 512, "images_per_sample": a.images_per_sample,
+                       "parallelism": f"dp{world}", "optimizer": "AdamW bf16 states + global-norm clip 1.0",
+                       "activation_recompute": "RMSNorm/SwiGLU only (no layer checkpointing)"},
+            "loss": train.get("loss"),
+            "roofline": train.get("roofline"),
+            "e2e_frac_mfma_peak": train.get("e2e_frac_mfma_peak"),
+            "denoise": denoise,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(a.seq_len)
+            except Exception as ex:  # the baseline is informational; never lose the GPU line
+                line["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -214,7 +214,9 @@ __global__ __launch_bounds__(256) void ce_fwd_bwd_kernel(const float* __restrict
 template <typename PT, typename ST>
 __global__ __launch_bounds__(256) void adamw_kernel(PT* __restrict__ p, const PT* __restrict__ g, ST* __restrict__ m,
                                                     ST* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                    float wd, float bc1, float bc2, float gscale) {
+                                                    float wd, float bc1, float bc2, float gscale,
+                                                    const float* __restrict__ gscale_dev) {
+    if (gscale_dev != nullptr) gscale *= gscale_dev[0];  // e.g. the clip coefficient, kept on device (no host sync)
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float pf = (float)p[i];
         const float gf = (float)g[i] * gscale;
@@ -466,8 +468,10 @@ int dllm_cross_entropy(const float* logits, const int64_t* labels, float* loss_r
     return dllm_check_launch();
 }
 
+// grad_scale_dev: optional device scalar multiplied into grad_scale (gradient-clipping coefficient without a host sync).
 int dllm_adamw(void* p, const void* g, void* m, void* v, int64_t n, int param_dtype, int state_dtype, float lr, float beta1,
-               float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream) {
+               float beta2, float eps, float weight_decay, int step, float grad_scale, const float* grad_scale_dev,
+               void* stream) {
     if (n < 0 || step < 1) return DLLM_ERR_SHAPE;
     if (n == 0) return DLLM_OK;
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
@@ -475,13 +479,13 @@ int dllm_adamw(void* p, const void* g, void* m, void* v, int64_t n, int param_dt
     hipStream_t s = (hipStream_t)stream;
     if (param_dtype == DLLM_BF16 && state_dtype == DLLM_BF16)
         hipLaunchKernelGGL((adamw_kernel<bf16, bf16>), dim3(gsz), dim3(256), 0, s, (bf16*)p, (const bf16*)g, (bf16*)m, (bf16*)v,
-                           n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                           n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, grad_scale_dev);
     else if (param_dtype == DLLM_BF16 && state_dtype == DLLM_F32)
         hipLaunchKernelGGL((adamw_kernel<bf16, float>), dim3(gsz), dim3(256), 0, s, (bf16*)p, (const bf16*)g, (float*)m,
-                           (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                           (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, grad_scale_dev);
     else if (param_dtype == DLLM_F32 && state_dtype == DLLM_F32)
         hipLaunchKernelGGL((adamw_kernel<float, float>), dim3(gsz), dim3(256), 0, s, (float*)p, (const float*)g, (float*)m,
-                           (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale);
+                           (float*)v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, grad_scale_dev);
     else
         return DLLM_ERR_DTYPE;
     return dllm_check_launch();

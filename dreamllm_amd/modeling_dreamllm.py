@@ -390,6 +390,16 @@ class DreamLLMPreTrainedModel(PreTrainedModel, FSDPMixin):
                 module.weight.data[module.padding_idx].zero_()
 
 
+def _extend_ignore(model, keys):
+    """plugin weights are saved separately as `{save_model_name}.bin` (modeling_dreamllm.py:828-830,1232-1234); the
+    attribute is a list in transformers 4.35 and a set in 5.x."""
+    cur = model._keys_to_ignore_on_save
+    if isinstance(cur, set):
+        model._keys_to_ignore_on_save = set(cur) | set(keys)
+    else:
+        model._keys_to_ignore_on_save = list(cur or []) + list(keys)
+
+
 def _special_id(config, token, nested=True):
     d = config.special_tokens2ids_dict
     return d["additional_special_tokens"][token] if nested else d[token]
@@ -427,7 +437,7 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
             if self.config.plugins_type[name] == "embedding":
                 setattr(self, name, deep_instantiate(init_kwargs).to(self.device, dtype=self.dtype))
                 keys_to_ignore = [f"model.{name}.{key}" for key in getattr(self, name).state_dict().keys()]
-                self._keys_to_ignore_on_save.extend(keys_to_ignore)
+                _extend_ignore(self, keys_to_ignore)
                 logger.info(f"Added the prefix keys of `model.{name}` to the list of keys to ignore on save.")
 
     def fsdp_ignored_modules(self) -> list:
@@ -572,7 +582,7 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
             if self.config.plugins_type[name] == "head":
                 setattr(self, name, deep_instantiate(init_kwargs).to(self.device, dtype=self.dtype))
                 keys_to_ignore = [f"{name}.{key}" for key in getattr(self, name).state_dict().keys()]
-                self._keys_to_ignore_on_save.extend(keys_to_ignore)
+                _extend_ignore(self, keys_to_ignore)
                 logger.info(f"Added the prefix keys of `{name}` to the list of keys to ignore on save.")
 
     def fsdp_ignored_modules(self) -> list:

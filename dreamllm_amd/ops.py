@@ -47,6 +47,33 @@ def _bf16(*ts):
 
 EPI = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3}
 
+# bench.py sets this to a list to time every launch of the MFMA GEMM/conv kernel with HIP events recorded on the stream the
+# kernel is launched on (torch's current stream): entries are (start_event, end_event, flops, tag).
+GEMM_PROFILE = None
+
+
+_GEMM_TAG = {(0, 0): "fwd", (0, 1): "dgrad", (1, 1): "wgrad", (1, 0): "tn"}
+
+
+class _GemmTimer:
+    __slots__ = ("s", "flops", "tag")
+
+    def __init__(self, flops, tag):
+        self.flops, self.tag, self.s = flops, tag, None
+
+    def __enter__(self):
+        if GEMM_PROFILE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.s is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            GEMM_PROFILE.append((self.s, e, self.flops, self.tag))
+        return False
+
 # --------------------------------------------------------------------------------------------- raw launches
 
 
@@ -133,9 +160,10 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     _bf16(a, b, bias, residual)
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
-    check("dllm_gemm_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
-          ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),
-          _stream())
+    with _GemmTimer(2.0 * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
+        check("dllm_gemm_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
+              ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),
+              _stream())
     return out
 
 
@@ -324,10 +352,12 @@ def cross_entropy_rows(logits, labels, dlogits=None, gscale=None):
     return loss_row
 
 
-def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, grad_scale_dev=None):
     _need_gpu(p, g, m, v)
-    check("dllm_adamw", _p(p), _p(g), _p(m), _p(v), p.numel(), _dt(p), _dt(m), float(lr), float(beta1), float(beta2),
-          float(eps), float(weight_decay), int(step), float(grad_scale), _stream())
+    if g.dtype != p.dtype:
+        g = g.to(p.dtype)
+    check("dllm_adamw", _p(p), _p(g.contiguous()), _p(m), _p(v), p.numel(), _dt(p), _dt(m), float(lr), float(beta1),
+          float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _p(grad_scale_dev), _stream())
 
 
 def sumsq_(x, out):
@@ -704,8 +734,9 @@ def conv2d_nhwc(x, w2d, CO, KH, KW, stride=1, pad=1, OH=None, OW=None, bias=None
     out = torch.empty(N, OH, OW, CO, dtype=out_dtype, device=x.device)
     if residual is not None and not residual.is_contiguous():
         residual = residual.contiguous()
-    check("dllm_conv2d_nhwc_bf16", _p(x), _p(w2d), _p(out), _p(bias), _p(residual), _p(image_bias), N, H, W, C, OH, OW, CO,
-          KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), _stream())
+    with _GemmTimer(2.0 * N * OH * OW * CO * KH * KW * C, "conv"):
+        check("dllm_conv2d_nhwc_bf16", _p(x), _p(w2d), _p(out), _p(bias), _p(residual), _p(image_bias), N, H, W, C, OH, OW,
+              CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), _stream())
     return out
 
 

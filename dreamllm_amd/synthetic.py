@@ -1,0 +1,59 @@
+"""Synthetic interleaved text-image batches with the tensor layout of the reference's data pipeline.
+
+Mirrors `DreamLLMDataset` joint mode + `DataCollatorForDreamLLMDataset` (omni/data/builders/builder_dreamllm.py:232-288,
+438-482): per sample `<s>` + K x ( text ++ <dream_start> <im_patch>x64 <dream_end> ++ <im_start> <im_patch>x256 <im_end> )
+++ text ++ `</s>`, right-padded with [PAD] (mask 0, labels -100); labels = ids with <im_patch>/<im_end>/<dream_end>
+positions set to -100 (:285-288); `images` ~ N(0,1) [B*K,3,224,224] (CLIP-normalised), `images_dm` ~ U(-1,1)
+[B*K,3,512,512].  Also emits the flat slot indices the model's sync-free splice path consumes.  SURVEY.md §8(d).
+"""
+from __future__ import annotations
+
+import torch
+
+from .tokenization_dreamllm import default_special_tokens2ids
+
+
+def make_interleaved_batch(batch_size=16, seq_len=2048, images_per_sample=2, n_dream=64, n_patch=256, base_vocab=32000,
+                           seed=1234, device="cpu", dtype=torch.bfloat16, ragged=False, image_size=224, dm_size=512,
+                           with_pixels=True):
+    g = torch.Generator().manual_seed(seed)
+    sp = default_special_tokens2ids(base_vocab)
+    add = sp["additional_special_tokens"]
+    pad, bos, eos = sp["[PAD]"], sp["<s>"], sp["</s>"]
+    K = images_per_sample
+    slot = (1 + n_dream + 1) + (1 + n_patch + 1)
+    ids = torch.full((batch_size, seq_len), pad, dtype=torch.long)
+    mask = torch.zeros(batch_size, seq_len, dtype=torch.long)
+    dream_pos, image_pos = [], []
+    for b in range(batch_size):
+        L = seq_len if not ragged else int(torch.randint(max(seq_len // 2, K * slot + 2 + K), seq_len + 1, (1,), generator=g))
+        text_total = L - 2 - K * slot
+        assert text_total >= K, "sequence too short for the requested number of image slots"
+        cuts = torch.sort(torch.randint(1, text_total, (K,), generator=g))[0].tolist() if text_total > K else list(range(1, K + 1))
+        lens = [cuts[0]] + [cuts[i] - cuts[i - 1] for i in range(1, K)] + [text_total - cuts[-1]]
+        row = [bos]
+        for k in range(K):
+            row += torch.randint(3, base_vocab, (lens[k],), generator=g).tolist()
+            dream_pos.append(b * seq_len + len(row))
+            row += [add["<dream_start>"]] + [add["<im_patch>"]] * n_dream + [add["<dream_end>"]]
+            image_pos.append(b * seq_len + len(row))
+            row += [add["<im_start>"]] + [add["<im_patch>"]] * n_patch + [add["<im_end>"]]
+        row += torch.randint(3, base_vocab, (lens[K],), generator=g).tolist() + [eos]
+        assert len(row) == L, (len(row), L)
+        ids[b, :L] = torch.tensor(row)
+        mask[b, :L] = 1
+    labels = ids.clone()
+    for t in ("<im_patch>", "<im_end>", "<dream_end>"):
+        labels[ids == add[t]] = -100
+    labels[mask == 0] = -100
+    dpos, ipos = torch.tensor(dream_pos), torch.tensor(image_pos)
+    batch = dict(
+        input_ids=ids.to(device), attention_mask=mask.to(device), labels=labels.to(device),
+        dream_index=(dpos[:, None] + 1 + torch.arange(n_dream)[None]).reshape(-1).to(device),
+        image_index=(ipos[:, None] + 1 + torch.arange(n_patch)[None]).reshape(-1).to(device),
+    )
+    if with_pixels:
+        n_img = batch_size * K
+        batch["images"] = torch.randn(n_img, 3, image_size, image_size, generator=g).to(dtype).to(device)
+        batch["images_dm"] = (torch.rand(n_img, 3, dm_size, dm_size, generator=g) * 2 - 1).to(dtype).to(device)
+    return batch

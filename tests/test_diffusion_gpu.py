@@ -221,10 +221,13 @@ def test_vae_encode_decode():
     mom = vae_ref.encode_moments(img, sd, od)
     z = bf16r(torch.randn(2, 4, 8, 8))
     dec = vae_ref.decode(z, sd, od)
+    sdb = {k: t.to(BF) for k, t in sd.items()}
+    e_enc = rel_l2(vae_ref.encode_moments(img.to(BF), sdb, od)[:, :4], mom[:, :4])
+    e_dec = rel_l2(vae_ref.decode(z.to(BF), sdb, od), dec)
     v = v.to(DEV, BF)
     dist = v.encode(img.to(DEV))
-    assert rel_l2(dist.mean, mom[:, :4]) < 1.5e-2
-    assert rel_l2(v.decode(z.to(DEV)), dec) < 1.5e-2
+    assert rel_l2(dist.mean, mom[:, :4]) <= 1.5 * e_enc + 2e-3
+    assert rel_l2(v.decode(z.to(DEV)), dec) <= 1.5 * e_dec + 2e-3
 
 
 # ----------------------------------------------------------------------------- StableDiffusionHead
