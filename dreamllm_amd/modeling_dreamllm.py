@@ -578,6 +578,7 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
     def init_plugin_modules(self):
         """modeling_dreamllm.py:1224-1235."""
         self.model.init_plugin_modules()
+        _extend_ignore(self, self.model._keys_to_ignore_on_save or [])  # the reference shares one class-level list
         for name, init_kwargs in self.config.plugins_init_kwargs.items():
             if self.config.plugins_type[name] == "head":
                 setattr(self, name, deep_instantiate(init_kwargs).to(self.device, dtype=self.dtype))

@@ -1,0 +1,160 @@
+/* dreamllm_hip.h -- C ABI of libdreamllm_hip.so, the gfx950 (MI355X / CDNA4) compute library behind the DreamLLM hot path.
+ *
+ * The reference (RunpeiDong/DreamLLM, "Omni") is 100 % Python: it has NO FFI / operator boundary of its own -- the seam
+ * is the set of PyTorch call sites listed per function below (paths relative to /root/reference/, "[ext]" = arithmetic
+ * that lives in the pinned third-party packages diffusers==0.24.0 / transformers==4.35.2, pyproject.toml:74,82).  This
+ * header is therefore the boundary WE define; the Python operator layer above it
+ * (dreamllm_amd/ops.py, ctypes) and the module layer above that (dreamllm_amd/modeling_*.py) mirror the reference's
+ * class / plugin API one-to-one.  INTEGRATION.md shows the binding a maintainer adds on the reference side.
+ *
+ * Conventions (every entry point):
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless stated; bf16 = IEEE bfloat16 bits;
+ *   - returns 0 (DLLM_OK) or a negative code: -1 bad shape, -2 unsupported dtype, -3 launch failure, -4 misaligned
+ *     pointer / stride (activations and row pitches must be multiples of 8 elements = 16 bytes);
+ *   - never allocates, frees or synchronises; asynchronous on `stream` (a hipStream_t passed as void*); workspaces are
+ *     caller-allocated; stateless and re-entrant (callable from autograd worker threads);
+ *   - there is no CPU fallback.
+ */
+#ifndef DREAMLLM_HIP_H
+#define DREAMLLM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLLM_OK 0
+#define DLLM_ERR_SHAPE (-1)
+#define DLLM_ERR_DTYPE (-2)
+#define DLLM_ERR_LAUNCH (-3)
+#define DLLM_ERR_ALIGN (-4)
+#define DLLM_BF16 0
+#define DLLM_F32 1
+
+/* ---------------------------------------------------------------------------------------------------- normalisation
+ * DreamLLMRMSNorm.forward, omni/models/dreamllm/modeling_dreamllm.py:77-91 (fp32 statistics, cast, then weight *), with
+ * an optional fused residual add in front (decoder residual stream, modeling_dreamllm.py:632,638).
+ * x,res,w,h_out,y: bf16; rstd: fp32[rows] (saved for backward).  res/h_out may be NULL together. */
+int dllm_rmsnorm_fwd(const void* x, const void* res, const void* w, void* h_out, void* y, float* rstd, int64_t rows, int D,
+                     float eps, void* stream);
+/* number of fp32 partial rows the norm backward kernels write: dw_partial = [nparts][D] floats */
+int dllm_norm_bwd_nparts(int64_t rows);
+/* autograd of the above: dx = rstd*(g - xhat*mean(g*xhat)) [+ dh_in]; dw_out[D] (dtype flag) via dw_partial, or NULLs. */
+int dllm_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* rstd, const void* dh_in, void* dx,
+                     float* dw_partial, void* dw_out, int dw_dtype, int64_t rows, int D, void* stream);
+/* torch.nn.LayerNorm as used by CLIPVisionModel [ext] (modeling_plugins.py:214-219,321-323), the optional
+ * post_layernorm (modeling_plugins.py:234-238) and BasicTransformerBlock.norm{1,2,3} of the UNet [ext]. */
+int dllm_layernorm_fwd(const void* x, const void* w, const void* b, void* y, float* mean, float* rstd, int64_t rows, int D,
+                       float eps, void* stream);
+int dllm_layernorm_bwd(const void* dy, const void* x, const void* w, const float* mean, const float* rstd, void* dx,
+                       float* dw_partial, float* db_partial, void* dw_out, void* db_out, int dw_dtype, int64_t rows, int D,
+                       void* stream);
+/* GroupNorm(32)(+SiLU) on NHWC activations: ResnetBlock2D.norm1/norm2, Transformer2DModel.norm, conv_norm_out of
+ * UNet2DConditionModel / AutoencoderKL [ext] (call sites modeling_plugins.py:511,556,815-821,842).
+ * x,y: bf16 [NB,HW,C]; mean,rstd: fp32 [NB,G]; ab: fp32 [NB,C,2] scratch; part: dllm_groupnorm_ws_floats() floats. */
+int64_t dllm_groupnorm_ws_floats(int NB, int HW, int C);
+int dllm_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, float* ab,
+                       float* part, int NB, int HW, int C, int G, float eps, int act, void* stream);
+/* input gradient only (affine frozen: modeling_plugins.py:405-407); c1,c2: fp32 [NB,G] scratch */
+int dllm_groupnorm_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean, const float* rstd,
+                       void* dx, float* c1, float* c2, float* part, int NB, int HW, int C, int G, int act, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------- contractions
+ * bf16 MFMA GEMM, fp32 accumulate: C[M,N] = epi(alpha * A*B + bias) + residual.  Replaces every nn.Linear on the path:
+ * q/k/v/o_proj modeling_dreamllm.py:273-276,336-338,395; gate/up/down_proj :219-221,237; lm_head :1216,1452; the
+ * projectors omni/models/projector/mlp_projector.py:19,23-27,39-50; and the linears inside CLIP / UNet / VAE [ext].
+ * layout_a: 0 = A[m][k] k-contiguous (lda = row pitch); 1 = A stored [K][lda], m contiguous (x^T without a transpose).
+ * layout_b: 0 = B given as [N][ldb] k-contiguous (nn.Linear weight [out,in]); 1 = B stored [K][ldb], n contiguous.
+ *   forward y = x W^T : (0,0);  dgrad dx = dy W : (0,1);  wgrad dW = dy^T x : (1,1).
+ * epi: 0 none, 1 exact-erf GELU, 2 quick-GELU (CLIP), 3 SiLU.  out_dtype DLLM_BF16 | DLLM_F32.  accumulate: C += . */
+int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
+                   int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
+                   int out_dtype, int accumulate, float alpha, void* stream);
+/* NHWC convolution (3x3 / 1x1) as implicit GEMM: ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D, Upsample2D,
+ * conv_in/conv_out of UNet2DConditionModel and AutoencoderKL [ext] (call sites modeling_plugins.py:511,556,815-821,842).
+ * x [NB,H,W,C] bf16, w [CO][KH*KW*C] bf16 (k = (kh,kw,ci)), out [NB,OH,OW,CO]; image_bias [NB,CO] = per-image
+ * time-embedding add; up2: nearest-2x upsample fused into the gather; even_only: transposed gather (dgrad of stride 2). */
+int dllm_conv2d_nhwc_bf16(const void* x, const void* w, void* out, const void* bias, const void* residual,
+                          const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
+                          int stride, int pad, int up2, int even_only, int epi, int out_dtype, void* stream);
+/* [NB,2H,2W,C] -> [NB,H,W,C] 2x2 sums: backward of F.interpolate(nearest, x2) in Upsample2D [ext]. */
+int dllm_sumpool2_nhwc(const void* in, void* out, int NB, int H, int W, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------- attention
+ * Flash attention forward: replaces eager attention modeling_dreamllm.py:357-379 and flash_attn_func /
+ * flash_attn_varlen_func :532-549 (causal, dropout 0, scale 1/sqrt(Dh), fp32 softmax, right padding via lengths instead
+ * of _upad_input :553-583), CLIP self-attention and the UNet self/cross attention [ext].
+ * q,o: [B,Sq,H,D] views (element strides sb,ss,sh; d contiguous); k,v: [B,Sk,Hkv,D] views sharing one stride set;
+ * D in {64,128}; H % Hkv == 0 (GQA, repeat_kv :242-251); seqlens int32[B] or NULL; lse fp32 [B,H,Sq] or NULL. */
+int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B, int H, int Hkv,
+                  int Sq, int Sk, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
+                  int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale, int causal, void* stream);
+/* its autograd: dq/dk/dv (dk,dv share strides; may alias slices of one packed dQKV buffer); delta fp32 [B,H,Sq] ws. */
+int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* o, const float* lse, float* delta,
+                  void* dq, void* dk, void* dv, const int* seqlens, int B, int H, int Hkv, int Sq, int Sk, int D, int64_t q_sb,
+                  int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
+                  int64_t dq_sb, int64_t dq_ss, int64_t dq_sh, int64_t dk_sb, int64_t dk_ss, int64_t dk_sh, float scale,
+                  int causal, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------- elementwise
+ * apply_rotary_pos_emb + rotate_half, modeling_dreamllm.py:176-209, in place on a [T,NH,D] view; cos/sin fp32
+ * [max_pos][D/2]; pos int64[T] or NULL (=> token index % S); backward = 1 applies the transpose rotation. */
+int dllm_rope(void* x, const float* cos_tab, const float* sin_tab, const int64_t* pos, int64_t T, int S, int NH, int D,
+              int64_t tok_stride, int64_t head_stride, int backward, void* stream);
+/* mode 0: silu(a)*b = DreamLLMMLP act_fn(gate)*up, modeling_dreamllm.py:237;  mode 1: gelu(a)*b = diffusers GEGLU [ext] */
+int dllm_glu_fwd(const void* a, const void* b, void* out, int64_t M, int F, int64_t lda, int64_t ldb, int64_t ldo, int mode,
+                 void* stream);
+int dllm_glu_bwd(const void* dout, const void* a, const void* b, void* da, void* db, int64_t M, int F, int64_t ldd, int64_t lda,
+                 int64_t ldb, int64_t ldda, int64_t lddb, int mode, void* stream);
+/* out = a + b[i % period]: residual adds outside a GEMM epilogue, CLIP position embedding [ext] */
+int dllm_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t period, void* stream);
+int dllm_add_rowgroup(const void* a, const void* b, void* out, int64_t groups, int64_t rows_per_group, int C, void* stream);
+/* stand-alone activations: 1 nn.GELU (MLPProjector, mlp_projector.py:40-44), 2 quick-GELU, 3 SiLU (time embedding [ext]) */
+int dllm_act_fwd(const void* x, void* out, int64_t n, int mode, void* stream);
+int dllm_act_bwd(const void* dy, const void* x, void* dx, int64_t n, int mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------- gather / splice
+ * embed_tokens lookup modeling_dreamllm.py:1066-1067 and the dream-state gather :1399-1418 */
+int dllm_gather_rows(const void* table, const int64_t* idx, void* out, int64_t n, int D, int64_t ld_t, int64_t ld_o,
+                     void* stream);
+/* the multimodal splice (dream queries :1081-1099, image features :1104-1141) as one index scatter: dst[idx[i]] = src[i] */
+int dllm_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int D, int64_t ld_s, int64_t ld_d,
+                      void* stream);
+/* deterministic nn.Embedding backward over id-sorted rows */
+int dllm_segment_sum_rows(const void* dy, const int64_t* order, const int64_t* seg_start, const int64_t* uid, void* dtable,
+                          int64_t nuniq, int D, int64_t ld_dy, int64_t ld_t, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------- losses
+ * logits.float() + CrossEntropyLoss(reduction="none") + masked mean, modeling_dreamllm.py:1453-1470: per-row loss and
+ * (optionally) bf16 dlogits scaled by the DEVICE scalar gscale (= dloss / n_valid), so the step has no host sync. */
+int dllm_cross_entropy(const float* logits, const int64_t* labels, float* loss_row, void* dlogits, const float* gscale,
+                       int64_t rows, int V, int64_t ld_logits, int64_t ld_dlogits, void* stream);
+/* F.mse_loss(model_pred.float(), target.float()), modeling_plugins.py:559: out += sum (pred - target)^2 ; and its grad */
+int dllm_mse_sum(const void* pred, const float* target, int64_t n, float* out, void* stream);
+int dllm_mse_bwd(const void* pred, const float* target, int64_t n, const float* gscale, void* dpred, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------- optimizer step
+ * torch.optim.AdamW as built by omni/train/trainer.py:392-465 and stepped at :799-821 (clip_grad_norm_ :807):
+ * fused update with optional device-side clip coefficient; sumsq accumulates ||g||^2 into a zeroed fp32 scalar. */
+int dllm_adamw(void* p, const void* g, void* m, void* v, int64_t n, int param_dtype, int state_dtype, float lr, float beta1,
+               float beta2, float eps, float weight_decay, int step, float grad_scale, const float* grad_scale_dev,
+               void* stream);
+int dllm_sumsq(const void* x, int64_t n, int dtype, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------- denoising loop
+ * One launch for modeling_plugins.py:824-833 (noise_pred.chunk(2), CFG combine, scheduler.step with deterministic DDIM)
+ * plus the next iteration's torch.cat([latents]*2) (:811): pred bf16 [2B,P,4] NHWC, latents fp32 [B,P,4] in place,
+ * next_in bf16 [2B,P,8] (channel-padded conv_in operand) or NULL. */
+int dllm_cfg_ddim_step(const void* pred, float* latents, void* next_in, int64_t n_half, int64_t unused, float guidance,
+                       float sqrt_at, float sqrt_1mat, float sqrt_aprev, float sqrt_1maprev, int v_prediction, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------- test probes
+ * hardware-convention probes used by tests/test_kernels_gpu.py (ds_read_b64_tr_b16 and MFMA 16x16x32 fragment layouts) */
+int dllm_probe_tr16(const void* in256, void* out256, void* stream);
+int dllm_probe_mfma16(const void* a, const void* b, float* out256, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DREAMLLM_HIP_H */

@@ -1,0 +1,117 @@
+"""CPU: drop-in surface of the reference: config fields, plugin contract, state_dict keys, registry,
+synthetic batch layout, host logic of the splice indices.  No kernels are launched."""
+import pytest
+import torch
+
+from dreamllm_amd.configuration_dreamllm import DreamLLMConfig, create_config_init_kwargs
+from dreamllm_amd.factory import TINY, build_dreamllm, plugin_configs
+from dreamllm_amd.modeling_dreamllm import DreamLLMDecoderLayer, DreamLLMForCausalMLM, DreamLLMModel, DreamLLMRMSNorm, _slot_indices
+from dreamllm_amd.modeling_plugins import (CLIPVisionEmbedding, DreamEmbedding, MultimodalEmbedding, MultimodalHead, PluginBase,
+                                            StableDiffusionHead)
+from dreamllm_amd.projector import build_projector
+from dreamllm_amd.synthetic import make_interleaved_batch
+from oracle import unet_ref
+
+TINY_CLIP = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=56)
+TINY_SD = dict(unet=unet_ref.tiny_config(64), vae=dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1))
+
+
+@pytest.fixture(scope="module")
+def tiny_model():
+    return build_dreamllm(TINY, device="cpu", dtype=torch.float32, clip=TINY_CLIP, diffusion=TINY_SD, num_dream_queries=8)
+
+
+def test_config_defaults_and_plugin_registry():
+    cfg = DreamLLMConfig()
+    assert (cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers, cfg.num_key_value_heads) == (4096, 11008, 32, 32)
+    assert cfg.loss_weight_vm == 10.0 and cfg.loss_weight_lm == 1.0 and cfg.rope_scaling is None
+    with pytest.raises(ValueError):
+        create_config_init_kwargs(dict(_class_="notatype", _name_="x", _plugin_type_="head"))
+    name = cfg.update_plugins(plugin_configs(4096)[0])
+    assert name == "dream_embedding" and cfg.plugins_type[name] == "embedding"
+    assert cfg.plugins_init_kwargs[name]["_target_"].endswith("modeling_plugins.DreamEmbedding")
+    with pytest.raises(ValueError):
+        DreamLLMConfig(rope_scaling={"type": "bogus", "factor": 2.0})
+    assert DreamLLMConfig.from_dict(cfg.to_dict()).plugins_type == cfg.plugins_type  # JSON round trip
+
+
+def test_state_dict_keys_match_reference_layout(tiny_model):
+    keys = set(tiny_model.state_dict().keys())
+    for k in ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight", "model.layers.0.self_attn.q_proj.weight",
+              "model.layers.0.self_attn.rotary_emb.inv_freq", "model.layers.1.mlp.down_proj.weight",
+              "model.layers.0.input_layernorm.weight", "model.layers.0.post_attention_layernorm.weight",
+              "model.dream_embedding.dream_queries", "model.clip_vision_embedding.projector.projector.weight",
+              "model.clip_vision_embedding.projector.projector.bias",
+              "model.clip_vision_embedding.clip_vision_model.vision_model.embeddings.class_embedding",
+              "model.clip_vision_embedding.clip_vision_model.vision_model.pre_layrnorm.weight",
+              "stable_diffusion_head.projector.projector.weight", "stable_diffusion_head.unet.conv_in.weight",
+              "stable_diffusion_head.unet.mid_block.attentions.0.transformer_blocks.0.attn2.to_k.weight",
+              "stable_diffusion_head.vae.encoder.conv_in.weight", "stable_diffusion_head.vae.quant_conv.weight"):
+        assert k in keys, k
+    assert "stable_diffusion_head.projector.projector.bias" not in keys  # bias=False on the SD side (modeling_plugins.py:389-391)
+
+
+def test_plugin_contract(tiny_model, tmp_path):
+    de, ce, sh = tiny_model.model.dream_embedding, tiny_model.model.clip_vision_embedding, tiny_model.stable_diffusion_head
+    assert isinstance(de, MultimodalEmbedding) and isinstance(ce, MultimodalEmbedding) and isinstance(sh, MultimodalHead)
+    assert issubclass(MultimodalHead, PluginBase) and PluginBase.initializer_range == 0.02
+    assert (de.plugin_type, ce.plugin_type, sh.plugin_type) == ("embedding", "embedding", "head")
+    assert de.embed_len == 8 and de.embed_dim == 256 and ce.embed_len == 16 and ce.embed_dim == 256
+    assert de(3).shape == (3, 8, 256)
+    assert de.fsdp_ignored_modules() == [] and ce.fsdp_ignored_modules() == [ce.clip_vision_model]
+    assert sh.fsdp_ignored_modules() == [sh.vae, sh.unet]
+    assert not any(p.requires_grad for p in sh.unet.parameters()) and sh.projector.projector.weight.requires_grad
+    assert set(de.config) == {"pretrained_model_name_or_path", "num_dream_queries", "embed_len", "embed_dim", "freeze_dream_queries"}
+    # save / load round trip in the reference's file layout ({save_model_name}.bin)
+    for p in (de, ce, sh):
+        p.save_model(str(tmp_path))
+    assert sorted(f.name for f in tmp_path.iterdir()) == ["clip_vision_embedding.bin", "dream_embedding.bin", "stable_diffusion_head.bin"]
+    de2 = DreamEmbedding(pretrained_model_name_or_path=str(tmp_path), num_dream_queries=8, embed_hidden_size=256)
+    assert torch.equal(de2.dream_queries, de.dream_queries)
+    with pytest.raises(NotImplementedError):
+        CLIPVisionEmbedding(TINY_CLIP, embed_hidden_size=64, freeze_clip_vision_model=False)
+    with pytest.raises(NotImplementedError):
+        StableDiffusionHead(TINY_SD, embed_hidden_size=64, freeze_unet=False)
+    with pytest.raises(ValueError):
+        sh.check_inputs(100, 128, 1, prompt_embeds=torch.zeros(1, 8, 256))
+
+
+def test_projector_registry():
+    cfg = dict(projector="linear", freeze_projector=False, depth=1, save_model_name="x", model_name_or_path=None)
+    p = build_projector(cfg, 32, 64, bias=True)
+    assert set(p.state_dict()) == {"projector.weight", "projector.bias"} and p.save_model_name == "x_projector"
+    m = build_projector(dict(cfg, projector="mlp", depth=3), 32, 64, bias=False)
+    assert set(m.state_dict()) == {"projector.0.weight", "projector.2.weight", "projector.4.weight"}
+    with pytest.raises(AssertionError):
+        build_projector(cfg, 32, 64, bias=None)
+    with pytest.raises(AssertionError):
+        build_projector(dict(cfg, projector="mlp", depth=1), 32, 64, bias=False)
+    with pytest.raises(ValueError):
+        build_projector(dict(cfg, projector="nope"), 32, 64, bias=False)
+
+
+def test_model_api_surface(tiny_model):
+    assert isinstance(tiny_model.model, DreamLLMModel) and isinstance(tiny_model.model.layers[0], DreamLLMDecoderLayer)
+    assert tiny_model.get_decoder() is tiny_model.model and tiny_model.get_output_embeddings() is tiny_model.lm_head
+    from transformers.pytorch_utils import ALL_LAYERNORM_LAYERS
+    assert DreamLLMRMSNorm in ALL_LAYERNORM_LAYERS
+    assert DreamLLMForCausalMLM.config_class is DreamLLMConfig and DreamLLMForCausalMLM._no_split_modules == ["DreamLLMDecoderLayer"]
+    ign = set(tiny_model._keys_to_ignore_on_save)
+    assert "stable_diffusion_head.projector.projector.weight" in ign and "model.dream_embedding.dream_queries" in ign
+    with pytest.raises(RuntimeError):  # CPU tensors never reach a silent fallback
+        tiny_model(input_ids=torch.ones(1, 8, dtype=torch.long))
+
+
+def test_synthetic_batch_layout_and_slot_indices():
+    b = make_interleaved_batch(3, 512, 1, n_dream=8, n_patch=16, seed=3, with_pixels=False, ragged=True)
+    ids, lab, am = b["input_ids"], b["labels"], b["attention_mask"]
+    sp = {"<dream_start>": 32006, "<im_start>": 32003, "<im_patch>": 32002, "<im_end>": 32004, "<dream_end>": 32007}
+    assert (ids[:, 0] == 1).all() and ((am[:, :-1] - am[:, 1:]) >= 0).all()  # bos first, right padding only
+    assert (lab[ids == sp["<im_patch>"]] == -100).all() and (lab[ids == sp["<im_end>"]] == -100).all()
+    assert (lab[ids == sp["<dream_start>"]] == sp["<dream_start>"]).all() and (lab[am == 0] == -100).all()
+    di, n = _slot_indices(ids, sp["<dream_start>"], 8)
+    ii, m = _slot_indices(ids, sp["<im_start>"], 16)
+    assert n == 3 and m == 3 and torch.equal(di, b["dream_index"]) and torch.equal(ii, b["image_index"])
+    assert (ids.view(-1)[di] == sp["<im_patch>"]).all() and (ids.view(-1)[ii + 16 - 15 * 0][-1] != -1)
+    full = make_interleaved_batch(2, 2048, 2, with_pixels=False)
+    assert full["attention_mask"].all() and full["dream_index"].numel() == 2 * 2 * 64 and full["image_index"].numel() == 2 * 2 * 256
