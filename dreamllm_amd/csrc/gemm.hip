@@ -12,7 +12,9 @@
 // (omni/models/projector/mlp_projector.py:19,39-44) and the linears/convs inside CLIPVisionModel and
 // UNet2DConditionModel ([ext]).
 //
-// Structure: 128x128x64 block tile, 256 threads = 4 waves (2x2), wave tile 64x64 = 4x4 MFMA 16x16x32 tiles.
+// Structure (template T): T=128: 128x128x64 block tile, 4 waves (2x2), wave tile 64x64 = 4x4 MFMA 16x16x32 tiles, 64 KiB LDS;
+//                         T=256: 256x256x64 block tile, 8 waves (2x4), wave tile 128x64 = 8x4 MFMA tiles, 128 KiB LDS
+//                         (one block per CU, 2 waves per SIMD; used when the grid still covers the 256 CUs >= 1.5x).
 // Operands are staged global -> registers -> LDS (double buffered, one barrier per K tile, the next tile's global
 // loads are in flight during the MFMAs).  k-contiguous tiles are read with ds_read_b128 from an XOR-swizzled
 // [rows][64] image; reduction-dim-strided tiles keep their natural [64][128] image and are read with the gfx950
@@ -23,11 +25,13 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int A_K = 0, A_M = 1, A_CONV = 2;
 constexpr int B_K = 0, B_N = 1;
 
 constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
+
+static int g_force_tile = 0;  // test/benchmark override: 0 auto, 128, 256
 
 struct ConvGeom {
     int H, W, C;     // physical input spatial dims and channels (NHWC)
@@ -62,22 +66,24 @@ struct GemmParams {
 __device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 // m-contiguous tile: [64 k rows][128 m] bf16, 256 B per row, 32-B slot s stored at s ^ f(krow),
 // f = (krow & 3) | ((krow >> 3) & 1) << 2: the 8 k rows one half-wave touches in a transpose read hit 8 distinct slots.
+template <int T>
 __device__ __forceinline__ int mc_off(int krow, int byte_in_row) {
     const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
-    return krow * 256 + ((((byte_in_row >> 5) ^ f)) << 5) + (byte_in_row & 31);
+    return krow * (2 * T) + ((((byte_in_row >> 5) ^ f)) << 5) + (byte_in_row & 31);
 }
 
 __device__ __forceinline__ bf16x8 frag_kc(const char* tile, int row, int kk, int lane) {
     return *reinterpret_cast<const bf16x8*>(tile + kc_off(row, kk * 4 + (lane >> 4)));
 }
 
+template <int T>
 __device__ __forceinline__ bf16x8 frag_mc(const char* tile, int mbase, int kk, int lane) {
     // lane (g = lane>>4, t = lane&15) receives m = mbase + t, k = kk*32 + g*8 + 0..7
     const int g = lane >> 4, t = lane & 15;
     const int k0 = kk * 32 + g * 8 + (t >> 2);
     const int bcol = mbase * 2 + (t & 3) * 8;
-    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + mc_off(k0, bcol)));
-    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + mc_off(k0 + 4, bcol)));
+    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + mc_off<T>(k0, bcol)));
+    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + mc_off<T>(k0 + 4, bcol)));
     union {
         struct { short4v a, b; } s;
         bf16x8 v;
@@ -92,48 +98,54 @@ struct Stage {
     bf16x8 v[4];
 };
 
-// k-contiguous operand: thread t loads rows (t>>3) + 32p, chunk t&7.
+// k-contiguous operand: thread t loads rows (t>>3) + (T/4)p, chunk t&7   (2T threads, T rows, 8 chunks per row).
+template <int T>
 __device__ __forceinline__ void gload_kc(Stage& s, const bf16* base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0,
                                          int64_t K, int tid) {
     const int chunk = tid & 7;
     const int64_t k = k0 + chunk * 8;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int64_t row = row0 + (tid >> 3) + 32 * p;
+        const int64_t row = row0 + (tid >> 3) + (T / 4) * p;
         if (row < nrows && k < K)
             s.v[p] = ld_bf16x8(base + row * ld + k);
         else
             s.v[p] = zero_bf16x8();
     }
 }
+template <int T>
 __device__ __forceinline__ void lstore_kc(const Stage& s, char* tile, int tid) {
     const int chunk = tid & 7;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int row = (tid >> 3) + 32 * p;
+        const int row = (tid >> 3) + (T / 4) * p;
         *reinterpret_cast<bf16x8*>(tile + kc_off(row, chunk)) = s.v[p];
     }
 }
-// m-contiguous operand ([K][ld] with the tile's 128 m/n columns contiguous): thread t loads k rows (t>>4)+16p, chunk t&15.
+// m-contiguous operand ([K][ld] with the tile's T m/n columns contiguous): T/8 chunks per k row, 16 k rows per pass.
+template <int T>
 __device__ __forceinline__ void gload_mc(Stage& s, const bf16* base, int64_t ld, int64_t col0, int64_t ncols, int64_t k0,
                                          int64_t K, int tid) {
-    const int c16 = tid & 15;
+    constexpr int CPR = T / 8;
+    const int c16 = tid % CPR;
     const int64_t col = col0 + c16 * 8;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int64_t k = k0 + (tid >> 4) + 16 * p;
+        const int64_t k = k0 + (tid / CPR) + 16 * p;
         if (k < K && col < ncols)
             s.v[p] = ld_bf16x8(base + k * ld + col);
         else
             s.v[p] = zero_bf16x8();
     }
 }
+template <int T>
 __device__ __forceinline__ void lstore_mc(const Stage& s, char* tile, int tid) {
-    const int c16 = tid & 15;
+    constexpr int CPR = T / 8;
+    const int c16 = tid % CPR;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int krow = (tid >> 4) + 16 * p;
-        *reinterpret_cast<bf16x8*>(tile + mc_off(krow, c16 * 16)) = s.v[p];
+        const int krow = (tid / CPR) + 16 * p;
+        *reinterpret_cast<bf16x8*>(tile + mc_off<T>(krow, c16 * 16)) = s.v[p];
     }
 }
 
@@ -142,10 +154,11 @@ struct ConvRows {
     int64_t img_base[4];  // element offset of the image (img * H * W * C), or -1 if the row is out of range
     int ih0[4], iw0[4];   // logical top-left input coordinate (oh*stride - pad, ow*stride - pad)
 };
+template <int T>
 __device__ __forceinline__ void conv_rows_init(ConvRows& r, const ConvGeom& g, int64_t row0, int64_t M, int tid) {
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const int64_t m = row0 + (tid >> 3) + 32 * p;
+        const int64_t m = row0 + (tid >> 3) + (T / 4) * p;
         if (m < M) {
             const int64_t hw = (int64_t)g.OH * g.OW;
             const int64_t img = m / hw;
@@ -161,6 +174,7 @@ __device__ __forceinline__ void conv_rows_init(ConvRows& r, const ConvGeom& g, i
         }
     }
 }
+template <int T>
 __device__ __forceinline__ void gload_conv(Stage& s, const bf16* base, const ConvGeom& g, const ConvRows& r, int64_t k0,
                                            int64_t K, int tid) {
     const int64_t k = k0 + (tid & 7) * 8;
@@ -186,12 +200,16 @@ __device__ __forceinline__ void gload_conv(Stage& s, const bf16* base, const Con
 }
 
 // ---- kernel -------------------------------------------------------------------------------------------------------
-template <int AL, int BL>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams P) {
+template <int AL, int BL, int T>
+__global__ __launch_bounds__(2 * T, 2) void gemm_bf16_kernel(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [buf][A 16 KiB | B 16 KiB]
+    constexpr int BM = T, BN = T;
+    constexpr int TILE_BYTES = T * BK * 2;   // one operand tile: 16 KiB (T=128) / 32 KiB (T=256)
+    constexpr int STAGE = 2 * TILE_BYTES;    // [buf][A | B]
+    constexpr int WC = T / 64;               // wave columns (each wave: T/2 rows x 64 cols)
+    constexpr int MI = T / 32;               // 16-row MFMA sub-tiles per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave / WC) * (T / 2), wn = (wave % WC) * 64;
 
     // XCD-aware, grouped tile order
     const int num_pid_m = (int)((P.M + BM - 1) / BM), num_pid_n = (int)((P.N + BN - 1) / BN);
@@ -211,39 +229,39 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams P) {
     const int pid_n = (wgid % in_group) / gsz;
     const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     Stage sa, sb;
     ConvRows crow;
-    if constexpr (AL == A_CONV) conv_rows_init(crow, P.cv, m0, P.M, tid);
+    if constexpr (AL == A_CONV) conv_rows_init<T>(crow, P.cv, m0, P.M, tid);
 
     auto gload = [&](int64_t k0) {
         if constexpr (AL == A_K)
-            gload_kc(sa, P.A, P.lda, m0, P.M, k0, P.K, tid);
+            gload_kc<T>(sa, P.A, P.lda, m0, P.M, k0, P.K, tid);
         else if constexpr (AL == A_M)
-            gload_mc(sa, P.A, P.lda, m0, P.M, k0, P.K, tid);
+            gload_mc<T>(sa, P.A, P.lda, m0, P.M, k0, P.K, tid);
         else
-            gload_conv(sa, P.A, P.cv, crow, k0, P.K, tid);
+            gload_conv<T>(sa, P.A, P.cv, crow, k0, P.K, tid);
         if constexpr (BL == B_K)
-            gload_kc(sb, P.B, P.ldb, n0, P.N, k0, P.K, tid);
+            gload_kc<T>(sb, P.B, P.ldb, n0, P.N, k0, P.K, tid);
         else
-            gload_mc(sb, P.B, P.ldb, n0, P.N, k0, P.K, tid);
+            gload_mc<T>(sb, P.B, P.ldb, n0, P.N, k0, P.K, tid);
     };
     auto lstore = [&](int buf) {
-        char* ta = smem + buf * 32768;
-        char* tb = ta + 16384;
+        char* ta = smem + buf * STAGE;
+        char* tb = ta + TILE_BYTES;
         if constexpr (AL == A_M)
-            lstore_mc(sa, ta, tid);
+            lstore_mc<T>(sa, ta, tid);
         else
-            lstore_kc(sa, ta, tid);
+            lstore_kc<T>(sa, ta, tid);
         if constexpr (BL == B_K)
-            lstore_kc(sb, tb, tid);
+            lstore_kc<T>(sb, tb, tid);
         else
-            lstore_mc(sb, tb, tid);
+            lstore_mc<T>(sb, tb, tid);
     };
 
     const int nt = (int)((P.K + BK - 1) / BK);
@@ -253,15 +271,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams P) {
 
     for (int t = 0; t < nt; ++t) {
         if (t + 1 < nt) gload((int64_t)(t + 1) * BK);
-        const char* ta = smem + (t & 1) * 32768;
-        const char* tb = ta + 16384;
+        const char* ta = smem + (t & 1) * STAGE;
+        const char* tb = ta + TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 fa[4], fb[4];
+            bf16x8 fa[MI], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MI; ++i) {
                 if constexpr (AL == A_M)
-                    fa[i] = frag_mc(ta, wm + i * 16, kk, lane);
+                    fa[i] = frag_mc<T>(ta, wm + i * 16, kk, lane);
                 else
                     fa[i] = frag_kc(ta, wm + i * 16 + (lane & 15), kk, lane);
             }
@@ -270,10 +288,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams P) {
                 if constexpr (BL == B_K)
                     fb[j] = frag_kc(tb, wn + j * 16 + (lane & 15), kk, lane);
                 else
-                    fb[j] = frag_mc(tb, wn + j * 16, kk, lane);
+                    fb[j] = frag_mc<T>(tb, wn + j * 16, kk, lane);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
@@ -285,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams P) {
     // ---- epilogue: lane holds C[m][n..n+3], m = m0+wm+i*16+(lane&15), n = n0+wn+j*16+(lane>>4)*4
     const bool vec_ok = ((P.N & 3) == 0) && ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
         const int64_t m = m0 + wm + i * 16 + (lane & 15);
         if (m >= P.M) continue;
 #pragma unroll
@@ -357,19 +375,28 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmParams P) {
     }
 }
 
-template <int AL, int BL>
-int launch_gemm(const GemmParams& P, hipStream_t stream) {
-    const int64_t tiles = cdiv64(P.M, BM) * cdiv64(P.N, BN);
-    if (tiles <= 0) return DLLM_OK;
+template <int AL, int BL, int T>
+int launch_gemm_t(const GemmParams& P, hipStream_t stream) {
+    const int64_t tiles = cdiv64(P.M, T) * cdiv64(P.N, T);
     if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+    constexpr int LDS = 2 * 2 * T * BK * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AL, BL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AL, BL, T>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL>), dim3((unsigned)tiles), dim3(256), 65536, stream, P);
+    hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, T>), dim3((unsigned)tiles), dim3(2 * T), LDS, stream, P);
     return dllm_check_launch();
+}
+
+// 256-tile when its grid still fills the 256 CUs at least 1.5x (one 8-wave block per CU), else the 128-tile.
+template <int AL, int BL>
+int launch_gemm(const GemmParams& P, hipStream_t stream) {
+    if (P.M <= 0 || P.N <= 0) return DLLM_OK;
+    const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);
+    if (g_force_tile == 256 || (g_force_tile == 0 && tiles256 >= 384)) return launch_gemm_t<AL, BL, 256>(P, stream);
+    return launch_gemm_t<AL, BL, 128>(P, stream);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -403,6 +430,13 @@ int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, cons
     if (layout_a == A_M && layout_b == B_N) return launch_gemm<A_M, B_N>(P, s);
     if (layout_a == A_M && layout_b == B_K) return launch_gemm<A_M, B_K>(P, s);
     return DLLM_ERR_SHAPE;
+}
+
+// tile-size override for tests / microbenchmarks (0 = automatic)
+int dllm_gemm_set_tile(int tile) {
+    if (tile != 0 && tile != 128 && tile != 256) return DLLM_ERR_SHAPE;
+    g_force_tile = tile;
+    return DLLM_OK;
 }
 
 // NHWC convolution as implicit GEMM: out[n,oh,ow,co] = sum_{kh,kw,ci} in[n,ih,iw,ci] * w[co,kh,kw,ci] (+bias, +residual).

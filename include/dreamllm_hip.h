@@ -71,6 +71,8 @@ int dllm_groupnorm_bwd(const void* dy, const void* x, const void* gamma, const v
 int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
                    int out_dtype, int accumulate, float alpha, void* stream);
+/* tile-size override for tests / microbenchmarks: 0 automatic, 128 or 256 (process-global) */
+int dllm_gemm_set_tile(int tile);
 /* NHWC convolution (3x3 / 1x1) as implicit GEMM: ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D, Upsample2D,
  * conv_in/conv_out of UNet2DConditionModel and AutoencoderKL [ext] (call sites modeling_plugins.py:511,556,815-821,842).
  * x [NB,H,W,C] bf16, w [CO][KH*KW*C] bf16 (k = (kh,kw,ci)), out [NB,OH,OW,CO]; image_bias [NB,CO] = per-image

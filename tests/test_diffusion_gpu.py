@@ -30,10 +30,13 @@ def _ops():
     (2, 16, 16, 64, 64, 3, "down"), (2, 8, 8, 128, 128, 3, "up"), (1, 16, 16, 64, 64, 3, "down_asym"),
     (2, 16, 16, 4, 64, 3, "same"), (2, 16, 16, 64, 4, 3, "same"),
 ])
-def test_conv_fwd_dgrad(N, H, W, CI, CO, K, mode):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_conv_fwd_dgrad(N, H, W, CI, CO, K, mode, tile):
     """Implicit-GEMM NHWC conv against F.conv2d (fp32, NCHW) incl. stride-2, fused nearest-upsample, asymmetric pad,
     channel-padded conv_in / 4-channel conv_out; input gradient through the flipped-weight conv."""
     from dreamllm_amd.unet import HipConv2d, _pad8
+    from dreamllm_amd import _lib
+    _lib.check("dllm_gemm_set_tile", tile)
     torch.manual_seed(N * H + CI + CO)
     conv = HipConv2d(CI, CO, K, mode=mode)
     conv.weight.data = bf16r(conv.weight.data)
@@ -62,6 +65,7 @@ def test_conv_fwd_dgrad(N, H, W, CI, CO, K, mode):
     if mode != "down_asym":
         y.backward(dy.permute(0, 2, 3, 1).contiguous().to(BF).to(DEV))
         assert rel_l2(xd.grad[..., :CI].permute(0, 3, 1, 2), xr.grad) < 4e-3
+    _lib.check("dllm_gemm_set_tile", 0)
 
 
 def test_conv_epilogue_image_bias_and_residual():

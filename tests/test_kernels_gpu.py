@@ -135,9 +135,18 @@ def test_layernorm_fwd_bwd(rows, D):
 
 
 # ----------------------------------------------------------------------------- GEMM
+@pytest.fixture(params=[128, 256])
+def gemm_tile(request):
+    """run the GEMM tests once per block-tile variant (128x128 / 4 waves and 256x256 / 8 waves)"""
+    from dreamllm_amd import _lib
+    _lib.check("dllm_gemm_set_tile", request.param)
+    yield request.param
+    _lib.check("dllm_gemm_set_tile", 0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (130, 200, 264), (1, 64, 8), (777, 1000, 1032),
                                    (512, 32008, 256)])
-def test_gemm_nt_forward(M, N, K):
+def test_gemm_nt_forward(M, N, K, gemm_tile):
     ops = _ops()
     torch.manual_seed(M + N + K)
     x, w = rnd(M, K), rnd(N, K, scale=0.05)
@@ -150,7 +159,7 @@ def test_gemm_nt_forward(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 264, 520), (64, 4096, 1024), (1000, 8, 136)])
-def test_gemm_dgrad_wgrad(M, N, K):
+def test_gemm_dgrad_wgrad(M, N, K, gemm_tile):
     """dx = dy W (A_K, B_N: transpose reads on the weight) and dW = dy^T x (A_M, B_N: transpose reads on both)."""
     ops = _ops()
     torch.manual_seed(M * 3 + N)
@@ -168,7 +177,7 @@ def test_gemm_dgrad_wgrad(M, N, K):
 
 
 @pytest.mark.parametrize("epi", [None, "gelu", "quick_gelu", "silu"])
-def test_gemm_epilogues(epi):
+def test_gemm_epilogues(epi, gemm_tile):
     ops = _ops()
     torch.manual_seed(5)
     M, N, K = 200, 328, 256

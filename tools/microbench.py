@@ -149,8 +149,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default="")
+    ap.add_argument("--tile", type=int, default=0, help="force the GEMM block tile (128/256; 0 = automatic)")
     a = ap.parse_args()
     sel = set(a.only.split(",")) if a.only else None
+    from dreamllm_amd import _lib
+    _lib.check("dllm_gemm_set_tile", a.tile)
     if a.out and os.path.exists(a.out):
         os.remove(a.out)
     benches = dict(norm=bench_norm, elementwise=bench_elementwise, attn=bench_attn, attn_bwd=bench_attn_bwd, gemm=bench_gemm)
