@@ -32,6 +32,7 @@ constexpr int B_K = 0, B_N = 1;
 constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
 
 static int g_force_tile = 0;  // test/benchmark override: 0 auto, 128, 256
+static int g_use_glds = 1;    // direct-to-LDS 256-tile kernel when eligible
 
 struct ConvGeom {
     int H, W, C;     // physical input spatial dims and channels (NHWC)
@@ -199,6 +200,83 @@ __device__ __forceinline__ void gload_conv(Stage& s, const bf16* base, const Con
     }
 }
 
+// ---- epilogue shared by both kernels: lane holds C[m][n..n+3], m = mbase+i*16+(lane&15), n = nbase+j*16+(lane>>4)*4
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[MI][4], int64_t mbase, int64_t nbase, int lane) {
+    const bool vec_ok = ((P.N & 3) == 0) && ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int64_t m = mbase + i * 16 + (lane & 15);
+        if (m >= P.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = nbase + j * 16 + (lane >> 4) * 4;
+            if (n >= P.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * P.alpha;
+            const int nvalid = (int)min((int64_t)4, P.N - n);
+            if (P.bias != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nvalid) v[r] += (float)P.bias[n + r];
+            }
+            if (P.rg_bias != nullptr) {
+                const bf16* rb = P.rg_bias + (m / P.rg_rows) * P.N + n;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nvalid) v[r] += (float)rb[r];
+            }
+            if (P.epi == EPI_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+            } else if (P.epi == EPI_QUICK_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+            } else if (P.epi == EPI_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+            }
+            if (vec_ok && nvalid == 4) {
+                if (P.residual != nullptr) {
+                    bf16x4 rv = ld_bf16x4(P.residual + m * P.ldr + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+                }
+                if (P.out_f32) {
+                    float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n;
+                    f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
+                    if (P.accumulate) o += *reinterpret_cast<f32x4*>(cp);
+                    *reinterpret_cast<f32x4*>(cp) = o;
+                } else {
+                    bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n;
+                    if (P.accumulate) {
+                        bf16x4 c = ld_bf16x4(cp);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (float)c[r];
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+                    st_bf16x4(cp, o);
+                }
+            } else {
+                for (int r = 0; r < nvalid; ++r) {
+                    float x = v[r];
+                    if (P.residual != nullptr) x += (float)P.residual[m * P.ldr + n + r];
+                    if (P.out_f32) {
+                        float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n + r;
+                        *cp = P.accumulate ? (*cp + x) : x;
+                    } else {
+                        bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n + r;
+                        *cp = (bf16)(P.accumulate ? ((float)*cp + x) : x);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- kernel -------------------------------------------------------------------------------------------------------
 template <int AL, int BL, int T>
 __global__ __launch_bounds__(2 * T, 2) void gemm_bf16_kernel(GemmParams P) {
@@ -300,79 +378,182 @@ __global__ __launch_bounds__(2 * T, 2) void gemm_bf16_kernel(GemmParams P) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds C[m][n..n+3], m = m0+wm+i*16+(lane&15), n = n0+wn+j*16+(lane>>4)*4
-    const bool vec_ok = ((P.N & 3) == 0) && ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
+    gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane);
+}
+
+
+// ---- direct-to-LDS variant (T = 256, K % 64 == 0, dense operands) -------------------------------------------------
+// Same tile geometry and LDS images as gemm_bf16_kernel<.., 256>, but tiles arrive through global_load_lds_dwordx4
+// (LDS-DMA: no staging VGPRs, no ds_write pass).  The DMA writes wave-uniform-base + lane*16, i.e. LDS stays linear, so
+// the XOR swizzles of the images are applied to the per-lane SOURCE address (within a 128/256-byte segment: coalescing is
+// unaffected).  Tile t+1 is issued before the MFMAs of tile t into the other buffer; one vmcnt(0)+barrier per K tile.
+// Rows/columns beyond M/N are clamped (they only feed outputs that are never stored); K must be a multiple of 64.
+#define GLDS16(gptr, lptr)                                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                           \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+__device__ __forceinline__ void glds_kc_tile(const bf16* base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, char* tile,
+                                             int wave, int lane) {
+    // 256 rows x 128 B: 32 groups of 8 rows (1 KiB); wave w issues groups 4w .. 4w+3
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int64_t m = m0 + wm + i * 16 + (lane & 15);
-        if (m >= P.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t n = n0 + wn + j * 16 + (lane >> 4) * 4;
-            if (n >= P.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * P.alpha;
-            const int nvalid = (int)min((int64_t)4, P.N - n);
-            if (P.bias != nullptr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nvalid) v[r] += (float)P.bias[n + r];
-            }
-            if (P.rg_bias != nullptr) {
-                const bf16* rb = P.rg_bias + (m / P.rg_rows) * P.N + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nvalid) v[r] += (float)rb[r];
-            }
-            if (P.epi == EPI_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
-            } else if (P.epi == EPI_QUICK_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
-            } else if (P.epi == EPI_SILU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-            }
-            if (vec_ok && nvalid == 4) {
-                if (P.residual != nullptr) {
-                    bf16x4 rv = ld_bf16x4(P.residual + m * P.ldr + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-                }
-                if (P.out_f32) {
-                    float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n;
-                    f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
-                    if (P.accumulate) o += *reinterpret_cast<f32x4*>(cp);
-                    *reinterpret_cast<f32x4*>(cp) = o;
-                } else {
-                    bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n;
-                    if (P.accumulate) {
-                        bf16x4 c = ld_bf16x4(cp);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)c[r];
-                    }
-                    bf16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-                    st_bf16x4(cp, o);
-                }
-            } else {
-                for (int r = 0; r < nvalid; ++r) {
-                    float x = v[r];
-                    if (P.residual != nullptr) x += (float)P.residual[m * P.ldr + n + r];
-                    if (P.out_f32) {
-                        float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n + r;
-                        *cp = P.accumulate ? (*cp + x) : x;
-                    } else {
-                        bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n + r;
-                        *cp = (bf16)(P.accumulate ? ((float)*cp + x) : x);
-                    }
-                }
-            }
-        }
+    for (int p = 0; p < 4; ++p) {
+        const int grp = wave * 4 + p;
+        const int r = grp * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        int64_t row = row0 + r;
+        row = row < nrows ? row : nrows - 1;
+        GLDS16(base + row * ld + k0 + c * 8, tile + grp * 1024);
     }
+}
+__device__ __forceinline__ void glds_mc_tile(const bf16* base, int64_t ld, int64_t col0, int64_t ncols, int64_t k0, char* tile,
+                                             int wave, int lane) {
+    // 64 k rows x 512 B: 32 groups of 2 k rows (1 KiB)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int grp = wave * 4 + p;
+        const int krow = grp * 2 + (lane >> 5);
+        const int pos = (lane & 31) * 16;                       // byte position inside the 512-B row image
+        const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+        const int lbyte = ((((pos >> 5) ^ f)) << 5) + (pos & 31);  // logical byte held at that position
+        int64_t col = col0 + (lbyte >> 1);
+        col = col < ncols ? col : ncols - 8;
+        GLDS16(base + (k0 + krow) * ld + col, tile + grp * 1024);
+    }
+}
+
+// Transpose reads issued as inline asm: with LDS-DMA in flight hipcc puts a vmcnt(0) in front of every
+// __builtin_amdgcn_ds_read_tr16_b64 (it cannot prove the read does not alias the DMA), which drains the prefetch of the
+// next tile right after it is issued.  The asm form is invisible to that pass; its completion is waited for explicitly
+// (tr_wait: lgkmcnt(0) naming every destination, so no consumer is scheduled above it).
+__device__ __forceinline__ uint32_t lds_addr(const char* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ void tr_read_asm(u32x2& dst, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <int T>
+__device__ __forceinline__ void frag_mc_issue(u32x2& lo, u32x2& hi, const char* tile, int mbase, int kk, int lane) {
+    const int g = lane >> 4, t = lane & 15;
+    const int k0 = kk * 32 + g * 8 + (t >> 2);
+    const int bcol = mbase * 2 + (t & 3) * 8;
+    tr_read_asm(lo, lds_addr(tile + mc_off<T>(k0, bcol)));
+    tr_read_asm(hi, lds_addr(tile + mc_off<T>(k0 + 4, bcol)));
+}
+__device__ __forceinline__ bf16x8 join_frag(u32x2 lo, u32x2 hi) {
+    union {
+        struct { u32x2 a, b; } s;
+        bf16x8 v;
+    } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(u32x2 (&lo)[N], u32x2 (&hi)[N]) {
+    if constexpr (N == 8)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
+                       "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7])
+                     :: "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+                     :: "memory");
+}
+
+template <int AL, int BL>
+__global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = 256, BM = T, BN = T;
+    constexpr int TILE_BYTES = T * BK * 2, STAGE = 2 * TILE_BYTES;
+    constexpr int WC = 4, MI = 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave / WC) * (T / 2), wn = (wave % WC) * 64;
+
+    const int num_pid_m = (int)((P.M + BM - 1) / BM), num_pid_n = (int)((P.N + BN - 1) / BN);
+    const int nwg = num_pid_m * num_pid_n;
+    int wgid;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int in_group = GROUP_M * num_pid_n;
+    const int group_id = wgid / in_group;
+    const int first_m = group_id * GROUP_M;
+    const int gsz = min(num_pid_m - first_m, GROUP_M);
+    const int pid_m = first_m + (wgid % in_group) % gsz;
+    const int pid_n = (wgid % in_group) / gsz;
+    const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN;
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int64_t k0, int buf) {
+        char* ta = smem + buf * STAGE;
+        char* tb = ta + TILE_BYTES;
+        if constexpr (AL == A_K)
+            glds_kc_tile(P.A, P.lda, m0, P.M, k0, ta, wave, lane);
+        else
+            glds_mc_tile(P.A, P.lda, m0, P.M, k0, ta, wave, lane);
+        if constexpr (BL == B_K)
+            glds_kc_tile(P.B, P.ldb, n0, P.N, k0, tb, wave, lane);
+        else
+            glds_mc_tile(P.B, P.ldb, n0, P.N, k0, tb, wave, lane);
+    };
+
+    const int nt = (int)(P.K / BK);
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) issue((int64_t)(t + 1) * BK, (t + 1) & 1);
+        const char* ta = smem + (t & 1) * STAGE;
+        const char* tb = ta + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 fa[MI], fb[4];
+            u32x2 alo[MI], ahi[MI], blo[4], bhi[4];
+            if constexpr (AL == A_M) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) frag_mc_issue<T>(alo[i], ahi[i], ta, wm + i * 16, kk, lane);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i] = frag_kc(ta, wm + i * 16 + (lane & 15), kk, lane);
+            }
+            if constexpr (BL == B_N) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) frag_mc_issue<T>(blo[j], bhi[j], tb, wn + j * 16, kk, lane);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = frag_kc(tb, wn + j * 16 + (lane & 15), kk, lane);
+            }
+            if constexpr (AL == A_M) {
+                tr_wait<MI>(alo, ahi);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) fa[i] = join_frag(alo[i], ahi[i]);
+            }
+            if constexpr (BL == B_N) {
+                tr_wait<4>(blo, bhi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = join_frag(blo[j], bhi[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane);
 }
 
 template <int AL, int BL, int T>
@@ -395,7 +576,22 @@ template <int AL, int BL>
 int launch_gemm(const GemmParams& P, hipStream_t stream) {
     if (P.M <= 0 || P.N <= 0) return DLLM_OK;
     const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);
-    if (g_force_tile == 256 || (g_force_tile == 0 && tiles256 >= 384)) return launch_gemm_t<AL, BL, 256>(P, stream);
+    if (g_force_tile == 256 || (g_force_tile == 0 && tiles256 >= 384)) {
+        if constexpr (AL != A_CONV) {
+            if (g_use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K)) {
+                constexpr int LDS = 2 * 2 * 256 * BK * 2;
+                static bool attr_set = false;
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<AL, BL>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL((gemm_glds_kernel<AL, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);
+                return dllm_check_launch();
+            }
+        }
+        return launch_gemm_t<AL, BL, 256>(P, stream);
+    }
     return launch_gemm_t<AL, BL, 128>(P, stream);
 }
 
@@ -434,8 +630,10 @@ int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, cons
 
 // tile-size override for tests / microbenchmarks (0 = automatic)
 int dllm_gemm_set_tile(int tile) {
-    if (tile != 0 && tile != 128 && tile != 256) return DLLM_ERR_SHAPE;
-    g_force_tile = tile;
+    // 0 auto, 128, 256 (register-staged 256 tile), 257 = 256 tile with the direct-to-LDS kernel where eligible
+    if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return DLLM_ERR_SHAPE;
+    g_use_glds = (tile == 0 || tile == 257);
+    g_force_tile = tile == 257 ? 256 : tile;
     return DLLM_OK;
 }
 
