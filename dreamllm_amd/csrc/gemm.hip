@@ -58,6 +58,8 @@ struct GemmParams {
     int out_f32;     // C dtype
     int accumulate;  // C += result
     float alpha;     // scale applied to the accumulator before bias
+    int splitk;      // > 1: blockIdx.y owns a K range and writes raw fp32 partials to ws[split][M][N]
+    float* ws;
     ConvGeom cv;
 };
 
@@ -201,8 +203,72 @@ __device__ __forceinline__ void gload_conv(Stage& s, const bf16* base, const Con
 }
 
 // ---- epilogue shared by both kernels: lane holds C[m][n..n+3], m = mbase+i*16+(lane&15), n = nbase+j*16+(lane>>4)*4
+// bias / per-image bias / activation / residual / dtype conversion for 4 consecutive outputs C[m][n..n+3]
+__device__ __forceinline__ void epilogue_store4(const GemmParams& P, int64_t m, int64_t n, float (&v)[4], bool vec_ok) {
+    const int nvalid = (int)min((int64_t)4, P.N - n);
+    if (P.bias != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) v[r] += (float)P.bias[n + r];
+    }
+    if (P.rg_bias != nullptr) {
+        const bf16* rb = P.rg_bias + (m / P.rg_rows) * P.N + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) v[r] += (float)rb[r];
+    }
+    if (P.epi == EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+    } else if (P.epi == EPI_QUICK_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+    } else if (P.epi == EPI_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+    }
+    if (vec_ok && nvalid == 4) {
+        if (P.residual != nullptr) {
+            bf16x4 rv = ld_bf16x4(P.residual + m * P.ldr + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        }
+        if (P.out_f32) {
+            float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n;
+            f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
+            if (P.accumulate) o += *reinterpret_cast<f32x4*>(cp);
+            *reinterpret_cast<f32x4*>(cp) = o;
+        } else {
+            bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n;
+            if (P.accumulate) {
+                bf16x4 c = ld_bf16x4(cp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)c[r];
+            }
+            bf16x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
+            st_bf16x4(cp, o);
+        }
+    } else {
+        for (int r = 0; r < nvalid; ++r) {
+            float x = v[r];
+            if (P.residual != nullptr) x += (float)P.residual[m * P.ldr + n + r];
+            if (P.out_f32) {
+                float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n + r;
+                *cp = P.accumulate ? (*cp + x) : x;
+            } else {
+                bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n + r;
+                *cp = (bf16)(P.accumulate ? ((float)*cp + x) : x);
+            }
+        }
+    }
+}
+
+// ---- epilogue shared by the kernels: lane holds C[m][n..n+3], m = mbase+i*16+(lane&15), n = nbase+j*16+(lane>>4)*4
 template <int MI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[MI][4], int64_t mbase, int64_t nbase, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[MI][4], int64_t mbase, int64_t nbase, int lane,
+                                              int split = 0) {
     const bool vec_ok = ((P.N & 3) == 0) && ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -212,68 +278,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
         for (int j = 0; j < 4; ++j) {
             const int64_t n = nbase + j * 16 + (lane >> 4) * 4;
             if (n >= P.N) continue;
+            if (P.splitk > 1) {  // raw fp32 partial; the reduce kernel applies the epilogue (N % 4 == 0 enforced by the host)
+                *reinterpret_cast<f32x4*>(P.ws + ((int64_t)split * P.M + m) * P.N + n) = acc[i][j];
+                continue;
+            }
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * P.alpha;
-            const int nvalid = (int)min((int64_t)4, P.N - n);
-            if (P.bias != nullptr) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nvalid) v[r] += (float)P.bias[n + r];
-            }
-            if (P.rg_bias != nullptr) {
-                const bf16* rb = P.rg_bias + (m / P.rg_rows) * P.N + n;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r < nvalid) v[r] += (float)rb[r];
-            }
-            if (P.epi == EPI_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
-            } else if (P.epi == EPI_QUICK_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
-            } else if (P.epi == EPI_SILU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-            }
-            if (vec_ok && nvalid == 4) {
-                if (P.residual != nullptr) {
-                    bf16x4 rv = ld_bf16x4(P.residual + m * P.ldr + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-                }
-                if (P.out_f32) {
-                    float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n;
-                    f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
-                    if (P.accumulate) o += *reinterpret_cast<f32x4*>(cp);
-                    *reinterpret_cast<f32x4*>(cp) = o;
-                } else {
-                    bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n;
-                    if (P.accumulate) {
-                        bf16x4 c = ld_bf16x4(cp);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (float)c[r];
-                    }
-                    bf16x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-                    st_bf16x4(cp, o);
-                }
-            } else {
-                for (int r = 0; r < nvalid; ++r) {
-                    float x = v[r];
-                    if (P.residual != nullptr) x += (float)P.residual[m * P.ldr + n + r];
-                    if (P.out_f32) {
-                        float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n + r;
-                        *cp = P.accumulate ? (*cp + x) : x;
-                    } else {
-                        bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n + r;
-                        *cp = (bf16)(P.accumulate ? ((float)*cp + x) : x);
-                    }
-                }
-            }
+            epilogue_store4(P, m, n, v, vec_ok);
         }
+    }
+}
+
+// deterministic split-K reduction + epilogue: one thread per 4 outputs
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams P) {
+    const int64_t n4 = P.N >> 2;
+    const int64_t total = P.M * n4;
+    const bool vec_ok = ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / n4, n = (i % n4) * 4;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < P.splitk; ++z) a += *reinterpret_cast<const f32x4*>(P.ws + ((int64_t)z * P.M + m) * P.N + n);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = a[r] * P.alpha;
+        epilogue_store4(P, m, n, v, vec_ok);
     }
 }
 
@@ -342,13 +371,20 @@ __global__ __launch_bounds__(2 * T, 2) void gemm_bf16_kernel(GemmParams P) {
             lstore_mc<T>(sb, tb, tid);
     };
 
-    const int nt = (int)((P.K + BK - 1) / BK);
-    gload(0);
-    lstore(0);
+    int t_begin = 0, nt = (int)((P.K + BK - 1) / BK);
+    if (P.splitk > 1) {
+        const int per = (nt + P.splitk - 1) / P.splitk;
+        t_begin = blockIdx.y * per;
+        nt = max(0, min(nt - t_begin, per));
+    }
+    if (nt > 0) {
+        gload((int64_t)t_begin * BK);
+        lstore(0);
+    }
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) gload((int64_t)(t + 1) * BK);
+        if (t + 1 < nt) gload((int64_t)(t_begin + t + 1) * BK);
         const char* ta = smem + (t & 1) * STAGE;
         const char* tb = ta + TILE_BYTES;
 #pragma unroll
@@ -378,7 +414,7 @@ __global__ __launch_bounds__(2 * T, 2) void gemm_bf16_kernel(GemmParams P) {
         __syncthreads();
     }
 
-    gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane);
+    gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane, blockIdx.y);
 }
 
 
@@ -567,7 +603,13 @@ int launch_gemm_t(const GemmParams& P, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, T>), dim3((unsigned)tiles), dim3(2 * T), LDS, stream, P);
+    const int sk = P.splitk > 1 ? P.splitk : 1;
+    hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, T>), dim3((unsigned)tiles, sk), dim3(2 * T), LDS, stream, P);
+    if (sk > 1) {
+        int64_t work = P.M * (P.N >> 2);
+        int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, P);
+    }
     return dllm_check_launch();
 }
 
@@ -576,6 +618,7 @@ template <int AL, int BL>
 int launch_gemm(const GemmParams& P, hipStream_t stream) {
     if (P.M <= 0 || P.N <= 0) return DLLM_OK;
     const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);
+    if (P.splitk > 1) return launch_gemm_t<AL, BL, 128>(P, stream);
     if (g_force_tile == 256 || (g_force_tile == 0 && tiles256 >= 384)) {
         if constexpr (AL != A_CONV) {
             if (g_use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K)) {
@@ -604,9 +647,22 @@ extern "C" {
 // layout_a: 0 = A[m][k] k-contiguous (lda = row pitch), 1 = A stored [K][lda] with m contiguous.
 // layout_b: 0 = B given as [N][ldb] k-contiguous (nn.Linear weight), 1 = B stored [K][ldb] with n contiguous.
 // epi: 0 none, 1 exact-erf GELU, 2 quick-GELU, 3 SiLU.  out_dtype: DLLM_BF16 / DLLM_F32.
+int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
+                          int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
+                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, void* stream);
+
 int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
                    int out_dtype, int accumulate, float alpha, void* stream) {
+    return dllm_gemm_bf16_splitk(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, layout_a, layout_b, epi, out_dtype,
+                                 accumulate, alpha, 1, nullptr, stream);
+}
+
+// splitk > 1: workspace = fp32 [splitk][M][N] (caller-allocated); requires N % 4 == 0.
+int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
+                          int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
+                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, void* stream) {
+    if (splitk > 1 && (workspace == nullptr || (N & 3))) return DLLM_ERR_SHAPE;
     if (M < 0 || N < 0 || K < 0) return DLLM_ERR_SHAPE;
     if (M == 0 || N == 0) return DLLM_OK;
     if (!aligned16(A) || !aligned16(B)) return DLLM_ERR_ALIGN;
@@ -620,12 +676,27 @@ int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, cons
     P.A = (const bf16*)A; P.B = (const bf16*)B; P.C = C; P.bias = (const bf16*)bias; P.residual = (const bf16*)residual;
     P.M = M; P.N = N; P.K = K; P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldr = ldr;
     P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = accumulate; P.alpha = alpha;
+    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace;
     hipStream_t s = (hipStream_t)stream;
     if (layout_a == A_K && layout_b == B_K) return launch_gemm<A_K, B_K>(P, s);
     if (layout_a == A_K && layout_b == B_N) return launch_gemm<A_K, B_N>(P, s);
     if (layout_a == A_M && layout_b == B_N) return launch_gemm<A_M, B_N>(P, s);
     if (layout_a == A_M && layout_b == B_K) return launch_gemm<A_M, B_K>(P, s);
     return DLLM_ERR_SHAPE;
+}
+
+// Split-K helper: number of K splits this library would like for an [M,N,K] problem (1 = none).  Small grids with a deep
+// reduction (UNet at batch 2: M = 128..2048, K = 5760..23040) otherwise leave most of the 256 CUs idle.
+int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || (N & 3)) return 1;
+    const int64_t tiles = cdiv64(M, 128) * cdiv64(N, 128);
+    const int64_t ktiles = cdiv64(K, BK);
+    if (tiles >= 128 || ktiles < 16) return 1;
+    int64_t want = cdiv64(384, tiles);          // aim at ~1.5 blocks per CU
+    int64_t maxs = ktiles / 8;                  // keep >= 8 K tiles (512 k) per split
+    int64_t s = want < maxs ? want : maxs;
+    if (s > 32) s = 32;
+    return s < 2 ? 1 : (int)s;
 }
 
 // tile-size override for tests / microbenchmarks (0 = automatic)
@@ -642,9 +713,24 @@ int dllm_gemm_set_tile(int tile) {
 // up2: the logical input is the nearest-2x upsampling of x (Upsample2D + conv fused).
 // even_only: transposed gather used for the dgrad of a stride-2 conv (logical stride 1 over a zero-stuffed grid).
 // image_bias: optional bf16 [NB, CO] added per image (ResnetBlock2D time_emb_proj broadcast), before the activation.
+int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
+                                 const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
+                                 int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,
+                                 float* workspace, void* stream);
+
 int dllm_conv2d_nhwc_bf16(const void* x, const void* w, void* out, const void* bias, const void* residual,
                           const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                           int stride, int pad, int up2, int even_only, int epi, int out_dtype, void* stream) {
+    return dllm_conv2d_nhwc_bf16_splitk(x, w, out, bias, residual, image_bias, NB, H, W, C, OH, OW, CO, KH, KW, stride, pad, up2,
+                                        even_only, epi, out_dtype, 1, nullptr, stream);
+}
+
+// splitk > 1: workspace = fp32 [splitk][NB*OH*OW][CO]; requires CO % 4 == 0.
+int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
+                                 const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
+                                 int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,
+                                 float* workspace, void* stream) {
+    if (splitk > 1 && (workspace == nullptr || (CO & 3))) return DLLM_ERR_SHAPE;
     if (NB < 0 || H <= 0 || W <= 0 || C <= 0 || CO <= 0 || OH <= 0 || OW <= 0) return DLLM_ERR_SHAPE;
     if (NB == 0) return DLLM_OK;
     if ((C & 7) != 0) return DLLM_ERR_ALIGN;
@@ -656,6 +742,7 @@ int dllm_conv2d_nhwc_bf16(const void* x, const void* w, void* out, const void* b
     P.lda = C; P.ldb = P.K; P.ldc = CO; P.ldr = CO;
     P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = 0; P.alpha = 1.0f;
     P.rg_bias = (const bf16*)image_bias; P.rg_rows = (int64_t)OH * OW;
+    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace;
     P.cv = ConvGeom{H, W, C, OH, OW, KH, KW, stride, pad, up2, even_only};
     return launch_gemm<A_CONV, B_K>(P, (hipStream_t)stream);
 }

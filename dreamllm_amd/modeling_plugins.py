@@ -467,13 +467,56 @@ class StableDiffusionHead(MultimodalHead):
         return guidance_rescale * noise_pred_rescaled + (1 - guidance_rescale) * noise_cfg
 
     @torch.no_grad()
+    def _denoise_loop_graph(self, latents, ctx_embeds, timesteps, sched, guidance_scale):
+        """Deterministic-DDIM + CFG loop body (modeling_plugins.py:809-839) as: [fill t] -> hipGraph replay of one UNet
+        forward on static NHWC buffers -> ONE fused kernel (CFG combine + DDIM update + next UNet input).  ~600 kernel
+        launches per step collapse into one graph launch, which is what the loop is bound by at B_img = 1.  The graph
+        (and its static buffers, including the cross-attention K/V of the conditioning tokens) is cached per shape."""
+        B, C, H, W = latents.shape
+        key = (B, H, W, tuple(ctx_embeds.shape))
+        cache = getattr(self, "_graph_cache", None)
+        if cache is None:
+            cache = self._graph_cache = {}
+        dev = latents.device
+        ent = cache.get(key)
+        ctx_now = self.unet.prepare_context(ctx_embeds)
+        if ent is None:
+            x_in = torch.zeros(2 * B, H, W, 8, dtype=self.dtype, device=dev)
+            t_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+            ctx_static = {k: [t.clone() for t in v] for k, v in ctx_now.items()}
+            emb_static = ctx_embeds.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up outside capture (lazy caches, kernel attributes)
+                for _ in range(2):
+                    self.unet(x_in, t_dev, emb_static, context_cache=ctx_static, nhwc_io=True, return_dict=False)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                pred = self.unet(x_in, t_dev, emb_static, context_cache=ctx_static, nhwc_io=True, return_dict=False)[0]
+            ent = cache[key] = dict(graph=graph, x_in=x_in, t=t_dev, ctx=ctx_static, pred=pred)
+        for k, v in ctx_now.items():
+            for dst, src in zip(ent["ctx"][k], v):
+                dst.copy_(src)
+        lat = latents.permute(0, 2, 3, 1).contiguous().float()  # NHWC fp32 master copy
+        x_in = ent["x_in"]
+        x_in.zero_()
+        x_in[:B, ..., :4] = lat.to(self.dtype)
+        x_in[B:, ..., :4] = lat.to(self.dtype)
+        for t in timesteps:
+            ent["t"].fill_(float(t))
+            ent["graph"].replay()
+            sched.step_cfg_fused_(ent["pred"], t, lat, x_in, guidance_scale)
+        return lat.permute(0, 3, 1, 2).contiguous()
+
+    @torch.no_grad()
     def pipeline(self, height: int | None = None, width: int | None = None, num_inference_steps: int = 50,
                  guidance_scale: float = 7.5, num_images_per_prompt: int | None = 1, eta: float = 0.0,
                  generator=None, latents=None, prompt_embeds=None, negative_prompt_embeds=None,
                  output_type: Literal["latent", "pt", "np", "pil"] | None = "pil",
                  callback: Callable[[int, int, torch.FloatTensor], None] | None = None, callback_steps: int = 1,
                  cross_attention_kwargs: dict[str, Any] | None = None, guidance_rescale: float = 0.0,
-                 scheduler=None):
+                 scheduler=None, use_graph: bool = True):
         """modeling_plugins.py:671-850.  `scheduler` optionally overrides the head's DDPM scheduler for the loop (the
         benchmark installs the deterministic DDIM eta=0 scheduler)."""
         height = height or self.unet.config.sample_size * self.vae_scale_factor
@@ -494,20 +537,25 @@ class StableDiffusionHead(MultimodalHead):
         timesteps = sched.timesteps
         latents = self.prepare_latents(batch_size * num_images_per_prompt, self.unet.config.in_channels, height, width,
                                        torch.float32, device, generator, latents)
-        ctx = self.unet.prepare_context(prompt_embeds)  # cross-attention K/V of the 64 dream tokens: once, not per step
-        for i, t in enumerate(timesteps.tolist()):
-            model_in = torch.cat([latents] * 2) if do_cfg else latents
-            model_in = sched.scale_model_input(model_in, t)
-            noise_pred = self.unet(model_in.to(self.dtype), t, encoder_hidden_states=prompt_embeds, context_cache=ctx,
-                                   return_dict=False)[0].float()
-            if do_cfg:
-                noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
-                noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
-                if guidance_rescale > 0.0:
-                    noise_pred = self._rescale_noise_cfg(noise_pred, noise_pred_text, guidance_rescale=guidance_rescale)
-            latents = sched.step(noise_pred, t, latents, eta=eta, generator=generator)
-            if callback is not None and i % callback_steps == 0:
-                callback(i, t, latents)
+        fused = (use_graph and do_cfg and guidance_rescale == 0.0 and eta == 0.0 and hasattr(sched, "step_cfg_fused_")
+                 and callback is None and num_images_per_prompt == 1 and self.unet.config.in_channels == 4)
+        if fused:
+            latents = self._denoise_loop_graph(latents, prompt_embeds, timesteps.tolist(), sched, guidance_scale)
+        else:
+            ctx = self.unet.prepare_context(prompt_embeds)  # cross-attention K/V of the dream tokens: once, not per step
+            for i, t in enumerate(timesteps.tolist()):
+                model_in = torch.cat([latents] * 2) if do_cfg else latents
+                model_in = sched.scale_model_input(model_in, t)
+                noise_pred = self.unet(model_in.to(self.dtype), t, encoder_hidden_states=prompt_embeds, context_cache=ctx,
+                                       return_dict=False)[0].float()
+                if do_cfg:
+                    noise_pred_uncond, noise_pred_text = noise_pred.chunk(2)
+                    noise_pred = noise_pred_uncond + guidance_scale * (noise_pred_text - noise_pred_uncond)
+                    if guidance_rescale > 0.0:
+                        noise_pred = self._rescale_noise_cfg(noise_pred, noise_pred_text, guidance_rescale=guidance_rescale)
+                latents = sched.step(noise_pred, t, latents, eta=eta, generator=generator)
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, latents)
         if output_type == "latent":
             return latents
         image = self.vae.decode((latents / self.vae.config.scaling_factor).to(self.dtype))

@@ -47,6 +47,8 @@ def _bf16(*ts):
 
 EPI = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3}
 
+SPLITK = True  # split-K for small grids with deep reductions (see dllm_gemm_splitk_hint)
+
 # bench.py sets this to a list to time every launch of the MFMA GEMM/conv kernel with HIP events recorded on the stream the
 # kernel is launched on (torch's current stream): entries are (start_event, end_event, flops, tag).
 GEMM_PROFILE = None
@@ -160,10 +162,12 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     _bf16(a, b, bias, residual)
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    sk = _lib.call("dllm_gemm_splitk_hint", M, N, K) if SPLITK else 1
+    ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
     with _GemmTimer(2.0 * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
-        check("dllm_gemm_bf16", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
+        check("dllm_gemm_bf16_splitk", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
               ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),
-              _stream())
+              sk, _p(ws), _stream())
     return out
 
 
@@ -734,9 +738,12 @@ def conv2d_nhwc(x, w2d, CO, KH, KW, stride=1, pad=1, OH=None, OW=None, bias=None
     out = torch.empty(N, OH, OW, CO, dtype=out_dtype, device=x.device)
     if residual is not None and not residual.is_contiguous():
         residual = residual.contiguous()
+    Mg = N * OH * OW
+    sk = _lib.call("dllm_gemm_splitk_hint", Mg, CO, KH * KW * C) if SPLITK else 1
+    ws = torch.empty(sk * Mg * CO, dtype=torch.float32, device=x.device) if sk > 1 else None
     with _GemmTimer(2.0 * N * OH * OW * CO * KH * KW * C, "conv"):
-        check("dllm_conv2d_nhwc_bf16", _p(x), _p(w2d), _p(out), _p(bias), _p(residual), _p(image_bias), N, H, W, C, OH, OW,
-              CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), _stream())
+        check("dllm_conv2d_nhwc_bf16_splitk", _p(x), _p(w2d), _p(out), _p(bias), _p(residual), _p(image_bias), N, H, W, C, OH,
+              OW, CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), sk, _p(ws), _stream())
     return out
 
 

@@ -71,6 +71,16 @@ int dllm_groupnorm_bwd(const void* dy, const void* x, const void* gamma, const v
 int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
                    int out_dtype, int accumulate, float alpha, void* stream);
+/* Split-K variants for small grids with deep reductions (UNet at batch 2): splitk > 1 writes fp32 partials to the caller's
+ * workspace [splitk][M][N] and a deterministic reduce kernel applies the epilogue.  dllm_gemm_splitk_hint suggests splitk. */
+int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K);
+int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
+                          int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
+                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, void* stream);
+int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
+                                 const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
+                                 int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,
+                                 float* workspace, void* stream);
 /* tile-size override for tests / microbenchmarks: 0 automatic, 128 or 256 (process-global) */
 int dllm_gemm_set_tile(int tile);
 /* NHWC convolution (3x3 / 1x1) as implicit GEMM: ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D, Upsample2D,

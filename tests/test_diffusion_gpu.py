@@ -29,6 +29,7 @@ def _ops():
     (2, 16, 16, 64, 128, 3, "same"), (1, 12, 20, 320, 320, 3, "same"), (3, 8, 8, 128, 64, 1, "same"),
     (2, 16, 16, 64, 64, 3, "down"), (2, 8, 8, 128, 128, 3, "up"), (1, 16, 16, 64, 64, 3, "down_asym"),
     (2, 16, 16, 4, 64, 3, "same"), (2, 16, 16, 64, 4, 3, "same"),
+    (2, 8, 8, 1280, 1280, 3, "same"), (2, 16, 16, 640, 640, 3, "down"),   # small grid, deep K: split-K path
 ])
 @pytest.mark.parametrize("tile", [128, 256])
 def test_conv_fwd_dgrad(N, H, W, CI, CO, K, mode, tile):

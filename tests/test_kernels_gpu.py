@@ -459,3 +459,24 @@ def test_flash_attn_autograd():
     o = ops.flash_attn(qd, kd, vd, causal=False)
     o.float().square().sum().backward()
     assert rel_l2(qd.grad, qr.grad) < 2e-2 and rel_l2(kd.grad, kr.grad) < 2e-2 and rel_l2(vd.grad, vr.grad) < 2e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 1280, 11520), (512, 640, 5760), (104, 328, 2048)])
+def test_gemm_splitk_small_grid(M, N, K):
+    """Small grids with deep K (UNet at batch 2) take the deterministic split-K path: all three layouts + fused epilogue."""
+    from dreamllm_amd import _lib
+    ops = _ops()
+    assert _lib.call("dllm_gemm_splitk_hint", M, N, K) > 1
+    torch.manual_seed(M + K)
+    x, w, b, r = rnd(M, K), rnd(N, K, scale=0.02), rnd(N), rnd(M, N)
+    ref = F.gelu(x.float() @ w.float().t() + b.float()) + r.float()
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), bias=b.to(DEV), epi="gelu", residual=r.to(DEV))
+    assert rel_l2(y, ref) < 4e-3
+    y2 = ops.linear_fwd(x.to(DEV), w.to(DEV), bias=b.to(DEV), epi="gelu", residual=r.to(DEV))
+    assert torch.equal(y, y2)  # deterministic reduction order
+    dy = rnd(K, N)  # wgrad-shaped: reduction over K rows
+    xx = rnd(K, M)
+    dw = ops.linear_wgrad(dy.to(DEV), xx.to(DEV), out_dtype=torch.float32)
+    assert rel_l2(dw, dy.float().t() @ xx.float()) < 1e-5
+    dx = ops.linear_dgrad(rnd(M, K).to(DEV) * 0 + x.to(DEV), rnd(K, N, seed=1).to(DEV))
+    assert rel_l2(dx, x.float() @ rnd(K, N, seed=1).float()) < 4e-3
