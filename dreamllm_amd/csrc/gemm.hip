@@ -156,6 +156,8 @@ __device__ __forceinline__ void lstore_mc(const Stage& s, char* tile, int tid) {
 struct ConvRows {
     int64_t img_base[4];  // element offset of the image (img * H * W * C), or -1 if the row is out of range
     int ih0[4], iw0[4];   // logical top-left input coordinate (oh*stride - pad, ow*stride - pad)
+    int64_t pix_off[4];   // plain modes: element offset of (img, ih0, iw0, 0) -- may lie before the image for halo rows
+    unsigned tapmask[4];  // plain modes: bit (kh*KW + kw) set when that tap reads inside the image
 };
 template <int T>
 __device__ __forceinline__ void conv_rows_init(ConvRows& r, const ConvGeom& g, int64_t row0, int64_t M, int tid) {
@@ -170,33 +172,68 @@ __device__ __forceinline__ void conv_rows_init(ConvRows& r, const ConvGeom& g, i
             r.img_base[p] = img * (int64_t)g.H * g.W * g.C;
             r.ih0[p] = oh * g.stride - g.pad;
             r.iw0[p] = ow * g.stride - g.pad;
+            r.pix_off[p] = r.img_base[p] + ((int64_t)r.ih0[p] * g.W + r.iw0[p]) * g.C;
+            unsigned mk = 0;
+            for (int kh = 0; kh < g.KH; ++kh)
+                for (int kw = 0; kw < g.KW; ++kw) {
+                    const int ih = r.ih0[p] + kh, iw = r.iw0[p] + kw;
+                    if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) mk |= 1u << (kh * g.KW + kw);
+                }
+            r.tapmask[p] = mk;
         } else {
             r.img_base[p] = -1;
             r.ih0[p] = 0;
             r.iw0[p] = 0;
+            r.pix_off[p] = 0;
+            r.tapmask[p] = 0;
         }
     }
 }
 template <int T>
 __device__ __forceinline__ void gload_conv(Stage& s, const bf16* base, const ConvGeom& g, const ConvRows& r, int64_t k0,
                                            int64_t K, int tid) {
-    const int64_t k = k0 + (tid & 7) * 8;
-    const bool kvalid = k < K;
-    const int tap = kvalid ? (int)(k / g.C) : 0;
-    const int ci = kvalid ? (int)(k - (int64_t)tap * g.C) : 0;
-    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    // 32-bit index math only (K = KH*KW*C < 2^31): one unsigned division per thread per K tile, none when the tile start is
+    // uniform and C >= 64 is a multiple of 8 (the chunk wraps into the next tap at most once)
+    const unsigned k0u = (unsigned)k0, C = (unsigned)g.C;
+    const unsigned k = k0u + (unsigned)(tid & 7) * 8u;
+    const bool kvalid = k < (unsigned)K;
+    unsigned tap = k0u / C;  // uniform across the block: scalarised by the compiler
+    unsigned ci = k0u - tap * C + (unsigned)(tid & 7) * 8u;
+    if (C >= 64u) {
+        if (ci >= C) {
+            ci -= C;
+            ++tap;
+        }
+    } else {
+        tap = k / C;
+        ci = k - tap * C;
+    }
+    const int kh = (int)(tap / (unsigned)g.KW), kw = (int)tap - kh * g.KW;
+    const bool plain = !(g.up_shift | g.even_only);
+    if (plain) {
+        // unconditional loads from a always-valid address + select: no exec-mask juggling around the 4 gathers
+        const int64_t tapoff = (int64_t)((kh * g.W + kw) * g.C + (int)ci);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool ok = kvalid && ((r.tapmask[p] >> tap) & 1u);
+            const bf16* src = base + (ok ? r.pix_off[p] + tapoff : (int64_t)0);
+            const bf16x8 v = ld_bf16x8(src);
+            s.v[p] = ok ? v : zero_bf16x8();
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         int ih = r.ih0[p] + kh, iw = r.iw0[p] + kw;
         bool ok = kvalid && r.img_base[p] >= 0 && ih >= 0 && iw >= 0;
-        if (g.even_only) ok = ok && ((ih & 1) == 0) && ((iw & 1) == 0);
-        if (g.up_shift | g.even_only) {
+        if (!plain) {
+            if (g.even_only) ok = ok && ((ih & 1) == 0) && ((iw & 1) == 0);
             ih >>= 1;
             iw >>= 1;
         }
         ok = ok && ih < g.H && iw < g.W;
         if (ok)
-            s.v[p] = ld_bf16x8(base + r.img_base[p] + ((int64_t)ih * g.W + iw) * g.C + ci);
+            s.v[p] = ld_bf16x8(base + r.img_base[p] + (int64_t)((ih * g.W + iw) * g.C + (int)ci));
         else
             s.v[p] = zero_bf16x8();
     }
@@ -613,15 +650,25 @@ int launch_gemm_t(const GemmParams& P, hipStream_t stream) {
     return dllm_check_launch();
 }
 
-// 256-tile when its grid still fills the 256 CUs at least 1.5x (one 8-wave block per CU), else the 128-tile.
+// Tile choice: estimated efficiency = (useful / padded output area) x (occupied / available block slots over the rounds the
+// grid needs on 256 CUs) x relative kernel speed (128-tile 0.85, register-staged 256-tile 1.0, direct-to-LDS 256-tile 1.15).
+static inline double tile_eff(int64_t M, int64_t N, int T, double speed) {
+    const int64_t tm = cdiv64(M, T), tn = cdiv64(N, T), tiles = tm * tn;
+    const int64_t slots = 256 * (T == 128 ? 2 : 1);
+    const int64_t rounds = cdiv64(tiles, slots);
+    return ((double)M * N) / ((double)tm * tn * T * T) * ((double)tiles / (double)(rounds * slots)) * speed;
+}
+
 template <int AL, int BL>
 int launch_gemm(const GemmParams& P, hipStream_t stream) {
     if (P.M <= 0 || P.N <= 0) return DLLM_OK;
     const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);
+    const bool glds_ok = (AL != A_CONV) && g_use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K);
+    const bool pick256 = tile_eff(P.M, P.N, 256, glds_ok ? 1.15 : 1.0) >= tile_eff(P.M, P.N, 128, 0.85);
     if (P.splitk > 1) return launch_gemm_t<AL, BL, 128>(P, stream);
-    if (g_force_tile == 256 || (g_force_tile == 0 && tiles256 >= 384)) {
+    if (g_force_tile == 256 || (g_force_tile == 0 && pick256)) {
         if constexpr (AL != A_CONV) {
-            if (g_use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K)) {
+            if (glds_ok) {
                 constexpr int LDS = 2 * 2 * 256 * BK * 2;
                 static bool attr_set = false;
                 if (!attr_set) {

@@ -102,6 +102,21 @@ def bench_attn_bwd(out):
              tflops_algorithmic=round(tf, 1), frac_mfma_peak=round(tf / PEAK_TF, 4))
 
 
+def bench_conv(out):
+    """3x3 NHWC implicit-GEMM conv at the SD-2.1 UNet training shapes (32 images)."""
+    for name, N, H, C, CO in [("unet L0 320->320 @64", 32, 64, 320, 320), ("unet L1 640->640 @32", 32, 32, 640, 640),
+                              ("unet L2 1280->1280 @16", 32, 16, 1280, 1280), ("unet up 2560->1280 @16", 32, 16, 2560, 1280),
+                              ("unet up 960->320 @64", 32, 64, 960, 320), ("vae 128->128 @512", 4, 512, 128, 128),
+                              ("unet L0 batch2", 2, 64, 320, 320), ("unet L3 batch2", 2, 8, 1280, 1280)]:
+        x = torch.randn(N, H, H, C, device="cuda").to(BF)
+        w = (torch.randn(CO, 9 * C, device="cuda") * 0.02).to(BF)
+        b = torch.zeros(CO, device="cuda", dtype=BF)
+        ms = timeit(lambda: ops.conv2d_nhwc(x, w, CO, 3, 3, bias=b))
+        tf = 2.0 * N * H * H * CO * 9 * C / ms / 1e9
+        emit(out, kernel="conv3x3_nhwc", name=name, N=N, H=H, C=C, CO=CO, ms=round(ms, 4), tflops=round(tf, 1),
+             frac_mfma_peak=round(tf / PEAK_TF, 4))
+
+
 def bench_norm(out):
     rows, D = 32768, 4096
     x = torch.randn(rows, D, device="cuda").to(BF)
@@ -156,7 +171,7 @@ def main():
     _lib.check("dllm_gemm_set_tile", a.tile)
     if a.out and os.path.exists(a.out):
         os.remove(a.out)
-    benches = dict(norm=bench_norm, elementwise=bench_elementwise, attn=bench_attn, attn_bwd=bench_attn_bwd, gemm=bench_gemm)
+    benches = dict(conv=bench_conv, norm=bench_norm, elementwise=bench_elementwise, attn=bench_attn, attn_bwd=bench_attn_bwd, gemm=bench_gemm)
     for name, fn in benches.items():
         if sel is None or name in sel:
             try:
