@@ -195,7 +195,10 @@ def main():
         tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get("gemm_bf16_kernel_hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                traffic = {"hbm_bytes_per_launch": tj.get("gemm_bf16_kernel_hbm_bytes_per_launch"), "shape": tj.get("shape"),
+                           "algorithmic_bytes": tj["per_launch"]["fwd  gemm_glds_kernel<0,0>"]["algorithmic_bytes"],
+                           "source": "profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"}
             except Exception:
                 traffic = None
         train = dict(

@@ -242,7 +242,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, int
         s += v * v;
     }
     s = block_sum<4>(s, scratch);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;  // per-block partial: no atomics => bit-identical on every DDP replica
+}
+
+// out[0] = sum(in[0..n)) in a fixed order (single block): final stage of the deterministic reductions
+__global__ __launch_bounds__(256) void reduce_sum_f32_kernel(const float* __restrict__ in, int64_t n, float* __restrict__ out) {
+    __shared__ float scratch[4];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += in[i];
+    s = block_sum<4>(s, scratch);
+    if (threadIdx.x == 0) out[0] = s;
 }
 
 // mean((a - b)^2) partial sums: out += sum (a-b)^2 ; dgrad (optional): da = 2 (a - b) * gscale[0] / n
@@ -491,18 +500,25 @@ int dllm_adamw(void* p, const void* g, void* m, void* v, int64_t n, int param_dt
     return dllm_check_launch();
 }
 
-// out (fp32 scalar, must be zeroed by the caller) += sum x^2
+// partials[0..DLLM_SUMSQ_PARTS) = per-block partial sums of x^2 (unused slots must be pre-zeroed by the caller); combine
+// all partial buffers with dllm_reduce_sum_f32.  Deterministic (no atomics): DDP replicas compute identical clip factors.
 int dllm_sumsq(const void* x, int64_t n, int dtype, float* out, void* stream) {
     if (n < 0) return DLLM_ERR_SHAPE;
     if (n == 0) return DLLM_OK;
     int g = grid_for(n);
-    if (g > 1024) g = 1024;
+    if (g > 256) g = 256;
     if (dtype == DLLM_BF16)
         hipLaunchKernelGGL(sumsq_kernel<bf16>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, n, out);
     else if (dtype == DLLM_F32)
         hipLaunchKernelGGL(sumsq_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, n, out);
     else
         return DLLM_ERR_DTYPE;
+    return dllm_check_launch();
+}
+
+int dllm_reduce_sum_f32(const float* in, int64_t n, float* out, void* stream) {
+    if (n < 0) return DLLM_ERR_SHAPE;
+    hipLaunchKernelGGL(reduce_sum_f32_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, out);
     return dllm_check_launch();
 }
 

@@ -364,8 +364,18 @@ def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0
           float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _p(grad_scale_dev), _stream())
 
 
-def sumsq_(x, out):
-    check("dllm_sumsq", _p(x), x.numel(), _dt(x), _p(out), _stream())
+SUMSQ_PARTS = 256
+
+
+def sumsq_partials_(x, partials):
+    """partials: zeroed fp32 [SUMSQ_PARTS] slice receiving per-block partial sums of x^2 (deterministic)."""
+    check("dllm_sumsq", _p(x), x.numel(), _dt(x), _p(partials), _stream())
+
+
+def reduce_sum_f32(x):
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check("dllm_reduce_sum_f32", _p(x), x.numel(), _p(out), _stream())
+    return out
 
 
 def add_bcast(a, b):

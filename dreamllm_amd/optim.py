@@ -27,10 +27,10 @@ class HipAdamW(torch.optim.Optimizer):
         grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
         if not grads:
             return None
-        acc = torch.zeros(1, dtype=torch.float32, device=grads[0].device)
-        for g in grads:
-            ops.sumsq_(g.contiguous(), acc)
-        norm = acc.sqrt()
+        parts = torch.zeros(len(grads), ops.SUMSQ_PARTS, dtype=torch.float32, device=grads[0].device)
+        for i, g in enumerate(grads):
+            ops.sumsq_partials_(g.contiguous(), parts[i])
+        norm = ops.reduce_sum_f32(parts.view(-1)).sqrt()
         self.last_grad_norm = norm
         return torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0)
 

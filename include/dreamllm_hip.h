@@ -148,11 +148,13 @@ int dllm_mse_bwd(const void* pred, const float* target, int64_t n, const float* 
 
 /* ---------------------------------------------------------------------------------------------------- optimizer step
  * torch.optim.AdamW as built by omni/train/trainer.py:392-465 and stepped at :799-821 (clip_grad_norm_ :807):
- * fused update with optional device-side clip coefficient; sumsq accumulates ||g||^2 into a zeroed fp32 scalar. */
+ * fused update with optional device-side clip coefficient; ||g||^2 is reduced deterministically (per-block partials +
+ * fixed-order final sum) so that data-parallel replicas derive bit-identical clip factors. */
 int dllm_adamw(void* p, const void* g, void* m, void* v, int64_t n, int param_dtype, int state_dtype, float lr, float beta1,
                float beta2, float eps, float weight_decay, int step, float grad_scale, const float* grad_scale_dev,
                void* stream);
-int dllm_sumsq(const void* x, int64_t n, int dtype, float* out, void* stream);
+int dllm_sumsq(const void* x, int64_t n, int dtype, float* partials256, void* stream); /* 256 per-block partials, no atomics */
+int dllm_reduce_sum_f32(const float* in, int64_t n, float* out, void* stream);        /* fixed-order final reduction */
 
 /* ---------------------------------------------------------------------------------------------------- denoising loop
  * One launch for modeling_plugins.py:824-833 (noise_pred.chunk(2), CFG combine, scheduler.step with deterministic DDIM)
