@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
                     const int qidx = wq0 + qt * 16 + t;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float p = exp2f(s[kt][qt][r] * sl2 - lse2[qt]);
+                        float p = fast_exp2(fmaf(s[kt][qt][r], sl2, -lse2[qt]));
                         if (need_mask) {
                             const int kidx = kv0 + kt * 16 + g * 4 + r;
                             if (kidx >= sk_len || (CAUSAL && kidx > qidx + coff)) p = 0.f;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
                     const int kidx = wk0 + kt * 16 + t;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float p = exp2f(s[kt][r] * sl2 - l4[r]);
+                        float p = fast_exp2(fmaf(s[kt][r], sl2, -l4[r]));
                         if (need_mask) {
                             const int qidx = qb0 + qt * 16 + g * 4 + r;
                             if (qidx >= sq_len || kidx >= sk_len || (CAUSAL && kidx > qidx + coff)) p = 0.f;

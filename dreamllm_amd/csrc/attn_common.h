@@ -79,10 +79,10 @@ struct TileStage {
         for (int p = 0; p < NP; ++p) {
             const int i = tid + NT * p;
             const int r = i / CPR, c = i % CPR;
-            if (row0 + r < nrows_valid)
-                v[p] = ld_bf16x8(base + (int64_t)(row0 + r) * row_stride + c * 8);
-            else
-                v[p] = zero_bf16x8();
+            // rows past the end are clamped to the last valid row (finite data; every use of them is masked), so the
+            // loads are unconditional: no exec-mask branches around the prefetch
+            const int row = min(row0 + r, nrows_valid - 1);
+            v[p] = ld_bf16x8(base + (int64_t)row * row_stride + c * 8);
         }
     }
     __device__ __forceinline__ void lstore_row(char* tile, int tid) const {
@@ -116,6 +116,8 @@ struct AttnParams {
     float scale;
     int causal;
 };
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32 (x <= 0 here)
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
             const int qrow = wq0 + qt * 16 + t;
 #pragma unroll
             for (int ds = 0; ds < DS; ++ds)
-                qf[qt][ds] = (qrow < sq_len) ? ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8) : zero_bf16x8();
+                qf[qt][ds] = ld_bf16x8(qbase + (int64_t)min(qrow, sq_len - 1) * P.q_ss + ds * 32 + g * 8);
         }
     }
 
@@ -121,37 +121,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const int qidx = wq0 + qt * 16 + t;
+                // running max in the RAW score domain (scale > 0 commutes with max); exp2 argument by one FMA per element
                 float mx = -INFINITY;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float x = s[kt][qt][r] * sl2;
+                        float x = s[kt][qt][r];
                         if (need_mask) {
                             const int kidx = kv0 + kt * 16 + g * 4 + r;
                             if (kidx >= sk_len || (CAUSAL && kidx > qidx + coff)) x = -INFINITY;
+                            s[kt][qt][r] = x;
                         }
-                        s[kt][qt][r] = x;
                         mx = fmaxf(mx, x);
                     }
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float m_new = fmaxf(m_run[qt], mx);
                 const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                const float alpha = exp2f(m_run[qt] - m_use);
+                const float alpha = fast_exp2((m_run[qt] - m_use) * sl2);
+                const float nm = -m_use * sl2;
                 float rs = 0.f;
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float p = exp2f(s[kt][qt][r] - m_use);
+                        const float p = fast_exp2(fmaf(s[kt][qt][r], sl2, nm));
                         s[kt][qt][r] = p;
                         rs += p;
                     }
                 l_run[qt] = l_run[qt] * alpha + rs;
                 m_run[qt] = m_new;
+                if (!__all(alpha == 1.0f)) {  // wave-uniform: skip the O rescale when no lane's running max moved
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
+                    for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
+                }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
                 for (int r = 0; r < 4; ++r) o[r] = (bf16)(oacc[dt][qt][r] * inv);
                 st_bf16x4(obase + (int64_t)qrow * P.o_ss + dt * 16 + g * 4, o);
             }
-            if (lsebase && g == 0) lsebase[qrow] = (valid && l > 0.f) ? (m_run[qt] * kLn2 + logf(l)) : 0.f;
+            if (lsebase && g == 0) lsebase[qrow] = (valid && l > 0.f) ? (m_run[qt] * P.scale + logf(l)) : 0.f;
         }
     }
 }

@@ -1,0 +1,23 @@
+"""Per-kernel PMC averages from a rocprofv3 --pmc run (rocpd sqlite): python tools/rocpd_pmc.py file.db [substr]"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+db = sqlite3.connect(sys.argv[1])
+c = db.cursor()
+sub = sys.argv[2] if len(sys.argv) > 2 else ""
+q = """select s.display_name, d.id, d.end - d.start, i.name, p.value from rocpd_kernel_dispatch d
+       join rocpd_info_kernel_symbol s on d.kernel_id = s.id join rocpd_pmc_event p on p.event_id = d.event_id
+       join rocpd_info_pmc i on p.pmc_id = i.id"""
+acc = defaultdict(lambda: defaultdict(list))
+dur = defaultdict(dict)
+for n, did, dt, cname, val in c.execute(q):
+    if sub in n:
+        k = n.replace("(anonymous namespace)::", "")[:70]
+        acc[k][cname].append(val)
+        dur[k][did] = dt
+for k, d in acc.items():
+    ds = list(dur[k].values())
+    print(f"{k}  launches={len(ds)} avg_ms={sum(ds) / len(ds) / 1e6:.3f}")
+    for cn, vals in sorted(d.items()):
+        print(f"    {cn:32s} {sum(vals) / len(vals):.4g}")
