@@ -32,6 +32,7 @@ constexpr int B_K = 0, B_N = 1;
 constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
 
 static int g_force_tile = 0;  // test/benchmark override: 0 auto, 128, 256
+static int g_dbg_noload = 0;
 static int g_use_glds = 1;    // direct-to-LDS 256-tile kernel when eligible
 
 struct ConvGeom {
@@ -58,6 +59,7 @@ struct GemmParams {
     int out_f32;     // C dtype
     int accumulate;  // C += result
     float alpha;     // scale applied to the accumulator before bias
+    int dbg_noload;  // benchmark-only: skip the K-loop prefetches (wrong results) to expose the compute+barrier ceiling
     int splitk;      // > 1: blockIdx.y owns a K range and writes raw fp32 partials to ws[split][M][N]
     float* ws;
     ConvGeom cv;
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmParams P) {
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) issue((int64_t)(t + 1) * BK, (t + 1) & 1);
+        if (t + 1 < nt && !P.dbg_noload) issue((int64_t)(t + 1) * BK, (t + 1) & 1);
         const char* ta = smem + (t & 1) * STAGE;
         const char* tb = ta + TILE_BYTES;
 #pragma unroll
@@ -723,7 +725,7 @@ int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bia
     P.A = (const bf16*)A; P.B = (const bf16*)B; P.C = C; P.bias = (const bf16*)bias; P.residual = (const bf16*)residual;
     P.M = M; P.N = N; P.K = K; P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldr = ldr;
     P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = accumulate; P.alpha = alpha;
-    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace;
+    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.dbg_noload = g_dbg_noload;
     hipStream_t s = (hipStream_t)stream;
     if (layout_a == A_K && layout_b == B_K) return launch_gemm<A_K, B_K>(P, s);
     if (layout_a == A_K && layout_b == B_N) return launch_gemm<A_K, B_N>(P, s);
@@ -749,9 +751,11 @@ int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K) {
 // tile-size override for tests / microbenchmarks (0 = automatic)
 int dllm_gemm_set_tile(int tile) {
     // 0 auto, 128, 256 (register-staged 256 tile), 257 = 256 tile with the direct-to-LDS kernel where eligible
-    if (tile != 0 && tile != 128 && tile != 256 && tile != 257) return DLLM_ERR_SHAPE;
-    g_use_glds = (tile == 0 || tile == 257);
-    g_force_tile = tile == 257 ? 256 : tile;
+    // 258: like 257 but WITHOUT the K-loop prefetches (wrong results; exposes the compute+barrier ceiling in microbenchmarks)
+    if (tile != 0 && tile != 128 && tile != 256 && tile != 257 && tile != 258) return DLLM_ERR_SHAPE;
+    g_use_glds = (tile == 0 || tile >= 257);
+    g_dbg_noload = (tile == 258);
+    g_force_tile = tile >= 257 ? 256 : tile;
     return DLLM_OK;
 }
 
