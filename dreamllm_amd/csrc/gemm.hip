@@ -21,6 +21,8 @@
 // transpose read ds_read_b64_tr_b16, so no operand is ever transposed in HBM.  The MFMA is issued with the operands
 // swapped (D^T = B^T A^T) so every lane ends up with 4 consecutive output columns of one row -> 8/16-byte stores.
 // blockIdx is remapped so each XCD (private 4 MiB L2) works on a contiguous group of tiles (GROUP_M swizzle).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -33,6 +35,7 @@ constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
 
 static int g_force_tile = 0;  // test/benchmark override: 0 auto, 128, 256
 static int g_dbg_noload = 0;
+static int g_glds_pipe = 1;   // software-pipelined direct-to-LDS kernel (default); 0 = plain direct-to-LDS kernel (tile mode 257/258)
 static int g_use_glds = 1;    // direct-to-LDS 256-tile kernel when eligible
 
 struct ConvGeom {
@@ -631,6 +634,162 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmParams P) {
     gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane);
 }
 
+// ---- software-pipelined direct-to-LDS variant ------------------------------------------------------------------------
+// Same tiles, LDS images and DMA as gemm_glds_kernel; what changes is the order inside a wave.  The plain kernel reads all
+// 12 fragments of a 32-deep k step, waits, then issues 32 MFMAs: after every barrier both waves of a SIMD sit in that wait
+// together and the matrix pipe idles (PMC: SQ_WAIT_ANY 46 % of wave time, MFMA busy 49 %).  Here a k step is 8 groups of
+// 4 MFMAs (one A fragment x the 4 B fragments); the A fragment of group g+1 (and, at a k-step boundary, the next 4 B
+// fragments) is requested before group g's MFMAs, so each wait is for data requested >= 64 matrix cycles earlier.  The
+// tile barrier sits before the LAST group of a tile: the wave has consumed the tile from LDS, crosses the barrier, requests
+// the first fragments of the next tile, and only then issues the last 4 MFMAs, which cover that LDS latency.
+// Every LDS read is inline asm with counted s_waitcnt lgkmcnt(n) (LDS returns in order), for two reasons: hipcc would
+// otherwise drain vmcnt before any LDS read it can see while LDS-DMA is in flight, and its scheduler clusters reads.
+template <bool MC>
+struct FragR {
+    u32x4 v;       // k-contiguous image: one ds_read_b128
+    u32x2 lo, hi;  // m-contiguous image: two ds_read_b64_tr_b16
+};
+template <bool MC, int IDX, int KK>
+__device__ __forceinline__ void fragr_issue(FragR<MC>& f, uint32_t base) {
+    if constexpr (MC) {
+        const uint32_t a = base ^ (uint32_t)(IDX << 5);  // 32-B slot (idx ^ f): bits 5..7 of the address hold f only
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(a), "n"(KK * 16384));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(a), "n"(KK * 16384 + 2048));
+    } else {
+        const uint32_t a = KK ? (base ^ 64u) : base;     // chunk (4*kk + g) ^ s = (g ^ s) ^ 4*kk
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.v) : "v"(a), "n"(IDX * 2048));
+    }
+}
+template <int N, bool MC>
+__device__ __forceinline__ void fragr_wait(FragR<MC>& f) {  // wait until at most N younger LDS operations are outstanding
+    if constexpr (MC)
+        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(N) : "memory");
+    else
+        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f.v) : "n"(N) : "memory");
+}
+template <bool MC>
+__device__ __forceinline__ void fragr_touch(FragR<MC>& f) {  // orders the consumers of f after the preceding wait
+    if constexpr (MC)
+        asm volatile("" : "+v"(f.lo), "+v"(f.hi));
+    else
+        asm volatile("" : "+v"(f.v));
+}
+template <bool MC>
+__device__ __forceinline__ bf16x8 fragr_value(const FragR<MC>& f) {
+    if constexpr (MC)
+        return join_frag(f.lo, f.hi);
+    else
+        return __builtin_bit_cast(bf16x8, f.v);
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int AL, int BL>
+__global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int T = 256, BM = T, BN = T;
+    constexpr int TILE_BYTES = T * BK * 2, STAGE = 2 * TILE_BYTES;
+    constexpr int WC = 4, MI = 8;
+    constexpr bool AMC = (AL == A_M), BMC = (BL == B_N);
+    constexpr int OA = AMC ? 2 : 1, OB = BMC ? 2 : 1;  // LDS operations per fragment
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave / WC) * (T / 2), wn = (wave % WC) * 64;
+
+    const int num_pid_m = (int)((P.M + BM - 1) / BM), num_pid_n = (int)((P.N + BN - 1) / BN);
+    const int nwg = num_pid_m * num_pid_n;
+    int wgid;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    constexpr int GROUP_M = 8;
+    const int in_group = GROUP_M * num_pid_n;
+    const int group_id = wgid / in_group;
+    const int first_m = group_id * GROUP_M;
+    const int gsz = min(num_pid_m - first_m, GROUP_M);
+    const int pid_m = first_m + (wgid % in_group) % gsz;
+    const int pid_n = (wgid % in_group) / gsz;
+    const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN;
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto issue = [&](int64_t k0, int buf) {
+        char* ta = smem + buf * STAGE;
+        char* tb = ta + TILE_BYTES;
+        if constexpr (AL == A_K)
+            glds_kc_tile(P.A, P.lda, m0, P.M, k0, ta, wave, lane);
+        else
+            glds_mc_tile(P.A, P.lda, m0, P.M, k0, ta, wave, lane);
+        if constexpr (BL == B_K)
+            glds_kc_tile(P.B, P.ldb, n0, P.N, k0, tb, wave, lane);
+        else
+            glds_mc_tile(P.B, P.ldb, n0, P.N, k0, tb, wave, lane);
+    };
+
+    // per-lane byte offset of fragment (idx 0, k step 0) inside an operand tile
+    const int lg = lane >> 4, lt = lane & 15;
+    const uint32_t s0 = lds_addr(smem);
+    const uint32_t offA = AMC ? (uint32_t)mc_off<T>(lg * 8 + (lt >> 2), wm * 2 + (lt & 3) * 8) : (uint32_t)kc_off(wm + lt, lg);
+    const uint32_t offB =
+        (uint32_t)TILE_BYTES + (BMC ? (uint32_t)mc_off<T>(lg * 8 + (lt >> 2), wn * 2 + (lt & 3) * 8) : (uint32_t)kc_off(wn + lt, lg));
+
+    FragR<AMC> fa[2];
+    FragR<BMC> fb[2][4];
+    uint32_t ab = s0 + offA, bb = s0 + offB;
+    auto first_reads = [&]() {
+        static_for<0, 4>([&](auto j) { fragr_issue<BMC, decltype(j)::value, 0>(fb[0][decltype(j)::value], bb); });
+        fragr_issue<AMC, 0, 0>(fa[0], ab);
+    };
+
+    const int nt = (int)(P.K / BK);
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    first_reads();
+
+    for (int t = 0; t < nt; ++t) {
+        // tile t+1 goes into the buffer tile t-1 was read from: every wave finished those reads before the last barrier
+        if (t + 1 < nt && P.dbg_noload != 1) issue(P.dbg_noload == 2 ? (int64_t)0 : (int64_t)(t + 1) * BK, (t + 1) & 1);
+        static_for<0, 16>([&](auto gc) {
+            constexpr int g = decltype(gc)::value, kk = g >> 3, i = g & 7;
+            if constexpr (g < 15) {
+                constexpr int kn = (g + 1) >> 3, in = (g + 1) & 7;
+                if constexpr (in == 0)
+                    static_for<0, 4>([&](auto j) { fragr_issue<BMC, decltype(j)::value, kn>(fb[kn][decltype(j)::value], bb); });
+                fragr_issue<AMC, in, kn>(fa[(g + 1) & 1], ab);
+                fragr_wait<OA + (in == 0 ? 4 * OB : 0)>(fa[g & 1]);
+            } else {
+                fragr_wait<0>(fa[g & 1]);
+                if (t + 1 < nt) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    ab = s0 + offA + (uint32_t)(((t + 1) & 1) * STAGE);
+                    bb = s0 + offB + (uint32_t)(((t + 1) & 1) * STAGE);
+                    first_reads();
+                }
+            }
+            if constexpr (i == 0) static_for<0, 4>([&](auto j) { fragr_touch(fb[kk][decltype(j)::value]); });
+            const bf16x8 va = fragr_value(fa[g & 1]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane);
+}
+
 template <int AL, int BL, int T>
 int launch_gemm_t(const GemmParams& P, hipStream_t stream) {
     const int64_t tiles = cdiv64(P.M, T) * cdiv64(P.N, T);
@@ -677,6 +836,16 @@ int launch_gemm(const GemmParams& P, hipStream_t stream) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<AL, BL>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
                     attr_set = true;
+                }
+                if (g_glds_pipe) {
+                    static bool attr2_set = false;
+                    if (!attr2_set) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<AL, BL>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                        attr2_set = true;
+                    }
+                    hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);
+                    return dllm_check_launch();
                 }
                 hipLaunchKernelGGL((gemm_glds_kernel<AL, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);
                 return dllm_check_launch();
@@ -752,9 +921,12 @@ int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K) {
 int dllm_gemm_set_tile(int tile) {
     // 0 auto, 128, 256 (register-staged 256 tile), 257 = 256 tile with the direct-to-LDS kernel where eligible
     // 258: like 257 but WITHOUT the K-loop prefetches (wrong results; exposes the compute+barrier ceiling in microbenchmarks)
-    if (tile != 0 && tile != 128 && tile != 256 && tile != 257 && tile != 258) return DLLM_ERR_SHAPE;
+    // 259: 257 with the software-pipelined kernel; 260: 259 without the K-loop prefetches (benchmark only)
+    // 263: 259 with every prefetch reading K tile 0 (wrong results; all loads hit in L2: isolates the DMA path from HBM/L2 misses)
+    if (tile != 0 && tile != 128 && (tile < 256 || tile > 260) && tile != 263) return DLLM_ERR_SHAPE;
     g_use_glds = (tile == 0 || tile >= 257);
-    g_dbg_noload = (tile == 258);
+    g_glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 263);
+    g_dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : 0);
     g_force_tile = tile >= 257 ? 256 : tile;
     return DLLM_OK;
 }
