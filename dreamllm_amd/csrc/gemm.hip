@@ -499,6 +499,28 @@ __device__ __forceinline__ void glds_mc_tile(const bf16* base, int64_t ld, int64
     }
 }
 
+// one 1-KiB group (p-th of this wave's four) of the tiles above, for kernels that spread the DMA issue over the k loop
+__device__ __forceinline__ void glds_kc_one(const bf16* base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, char* tile,
+                                            int wave, int lane, int p) {
+    const int grp = wave * 4 + p;
+    const int r = grp * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int64_t row = row0 + r;
+    row = row < nrows ? row : nrows - 1;
+    GLDS16(base + row * ld + k0 + c * 8, tile + grp * 1024);
+}
+__device__ __forceinline__ void glds_mc_one(const bf16* base, int64_t ld, int64_t col0, int64_t ncols, int64_t k0, char* tile,
+                                            int wave, int lane, int p) {
+    const int grp = wave * 4 + p;
+    const int krow = grp * 2 + (lane >> 5);
+    const int pos = (lane & 31) * 16;
+    const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+    const int lbyte = ((((pos >> 5) ^ f)) << 5) + (pos & 31);
+    int64_t col = col0 + (lbyte >> 1);
+    col = col < ncols ? col : ncols - 8;
+    GLDS16(base + (k0 + krow) * ld + col, tile + grp * 1024);
+}
+
 // Transpose reads issued as inline asm: with LDS-DMA in flight hipcc puts a vmcnt(0) in front of every
 // __builtin_amdgcn_ds_read_tr16_b64 (it cannot prove the read does not alias the DMA), which drains the prefetch of the
 // next tile right after it is issued.  The asm form is invisible to that pass; its completion is waited for explicitly
@@ -752,6 +774,23 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
         fragr_issue<AMC, 0, 0>(fa[0], ab);
     };
 
+    // q-th of the wave's 8 DMA instructions for one K tile (4 per operand)
+    auto issue_one = [&](int64_t k0, int buf, int q) {
+        char* ta = smem + buf * STAGE;
+        char* tb = ta + TILE_BYTES;
+        if (q < 4) {
+            if constexpr (AL == A_K)
+                glds_kc_one(P.A, P.lda, m0, P.M, k0, ta, wave, lane, q);
+            else
+                glds_mc_one(P.A, P.lda, m0, P.M, k0, ta, wave, lane, q);
+        } else {
+            if constexpr (BL == B_K)
+                glds_kc_one(P.B, P.ldb, n0, P.N, k0, tb, wave, lane, q - 4);
+            else
+                glds_mc_one(P.B, P.ldb, n0, P.N, k0, tb, wave, lane, q - 4);
+        }
+    };
+
     const int nt = (int)(P.K / BK);
     issue(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -760,9 +799,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
 
     for (int t = 0; t < nt; ++t) {
         // tile t+1 goes into the buffer tile t-1 was read from: every wave finished those reads before the last barrier
-        if (t + 1 < nt && P.dbg_noload != 1) issue(P.dbg_noload == 2 ? (int64_t)0 : (int64_t)(t + 1) * BK, (t + 1) & 1);
+        const bool pf = (t + 1 < nt) && P.dbg_noload != 1;
+        const int64_t kpf = P.dbg_noload == 2 ? (int64_t)0 : (int64_t)(t + 1) * BK;
         static_for<0, 16>([&](auto gc) {
             constexpr int g = decltype(gc)::value, kk = g >> 3, i = g & 7;
+            if constexpr (g < 8) {  // one DMA instruction per group over the first k step: no 64-KiB burst per CU
+                if (pf) issue_one(kpf, (t + 1) & 1, g);
+            }
             if constexpr (g < 15) {
                 constexpr int kn = (g + 1) >> 3, in = (g + 1) & 7;
                 if constexpr (in == 0)
