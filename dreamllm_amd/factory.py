@@ -31,7 +31,7 @@ def _on(device, dtype):
 
 
 def plugin_configs(hidden_size, clip="openai/clip-vit-large-patch14", diffusion="sd21-base", num_dream_queries=64,
-                   with_clip=True, with_sd=True):
+                   with_clip=True, with_sd=True, sdxl=False, global_condition_hidden_size=1280, freeze_clip_projector=False):
     """The three `ConfigAndInitKwargs` of projects/dreamllm/configs/common.py with this package's classes as `_class_`."""
     cfgs = [create_config_init_kwargs(dict(_class_=DreamEmbedding, _name_="dream_embedding", _plugin_type_="embedding",
                                            pretrained_model_name_or_path=None, num_dream_queries=num_dream_queries,
@@ -41,12 +41,20 @@ def plugin_configs(hidden_size, clip="openai/clip-vit-large-patch14", diffusion=
             _class_=CLIPVisionEmbedding, _name_="clip_vision_embedding", _plugin_type_="embedding", projector_type="linear",
             projector_depth=1, clip_vision_model_name_or_path=clip, pretrained_model_name_or_path=None,
             embed_hidden_size=hidden_size, use_additional_post_layernorm=False, select_layer=-2,
-            freeze_clip_vision_model=True, freeze_embedding_layers=True, freeze_projector=False, local_files_only=True)))
-    if with_sd:
+            freeze_clip_vision_model=True, freeze_embedding_layers=True, freeze_projector=freeze_clip_projector,
+            local_files_only=True)))
+    if with_sd and not sdxl:
         cfgs.append(create_config_init_kwargs(dict(
             _class_=StableDiffusionHead, _name_="stable_diffusion_head", _plugin_type_="head", projector_type="linear",
             projector_depth=1, diffusion_name_or_path=diffusion, pretrained_model_name_or_path=None,
             embed_hidden_size=hidden_size, freeze_vae=True, freeze_unet=True, freeze_projector=False, local_files_only=True)))
+    if with_sd and sdxl:  # projects/dreamllm_sdxl/configs/common.py:43-58: same plugin NAME, SDXL class
+        from .modeling_plugins_sdxl import StableDiffusionXLHead
+        cfgs.append(create_config_init_kwargs(dict(
+            _class_=StableDiffusionXLHead, _name_="stable_diffusion_head", _plugin_type_="head", projector_type="linear",
+            projector_depth=1, diffusion_name_or_path=diffusion, pretrained_model_name_or_path=None,
+            embed_hidden_size=hidden_size, global_condition_hidden_size=global_condition_hidden_size, freeze_vae=True,
+            freeze_unet=True, freeze_projector=False, local_files_only=True)))
     return cfgs
 
 
@@ -65,3 +73,31 @@ def build_dreamllm(llm=None, device="cuda", dtype=torch.bfloat16, seed=0, base_v
         model = DreamLLMForCausalMLM(cfg)
         model.init_plugin_modules()
     return model.to(device=device, dtype=dtype)
+
+
+def build_dreamllm_sdxl(llm=None, device="cuda", dtype=torch.bfloat16, seed=0, base_vocab=32000,
+                        clip="openai/clip-vit-large-patch14", diffusion="sdxl-base", with_clip=True, num_dream_queries=196,
+                        global_condition_hidden_size=1280, stage1=True):
+    """Random-init DreamLLM-SDXL (projects/dreamllm_sdxl/configs/{common,stage1/base}.py): 196 dream queries, SDXL head.
+    `stage1=True` applies the stage-I freeze policy of stage1/base.py:27-37,47-53: LLM, embeddings, lm_head, CLIP and its
+    projector frozen; dream queries + the head's two projectors trainable; loss weights lm 0 / vm 1."""
+    from .modeling_dreamllm_sdxl import DreamLLMSDXLConfig, DreamLLMSDXLForCausalMLM, default_special_tokens2ids as sdxl_ids
+    llm = dict(VICUNA_7B if llm is None else llm)
+    sp = sdxl_ids(base_vocab)
+    vocab = base_vocab + 1 + len(sp["additional_special_tokens"])  # [PAD] + 8 added tokens -> 32009
+    cfg = DreamLLMSDXLConfig(vocab_size=vocab, pad_token_id=sp["[PAD]"], special_tokens2ids_dict=sp,
+                             loss_weight_lm=0.0 if stage1 else 1.0, loss_weight_vm=1.0 if stage1 else 10.0, **llm)
+    for pc in plugin_configs(llm["hidden_size"], clip, diffusion, num_dream_queries, with_clip, True, sdxl=True,
+                             global_condition_hidden_size=global_condition_hidden_size, freeze_clip_projector=stage1):
+        cfg.update_plugins(pc)
+    torch.manual_seed(seed)
+    with _on(device, dtype):
+        model = DreamLLMSDXLForCausalMLM(cfg)
+        model.init_plugin_modules()
+    model = model.to(device=device, dtype=dtype)
+    if stage1:
+        model.model.embed_tokens.requires_grad_(False)
+        model.model.layers.requires_grad_(False)
+        model.model.norm.requires_grad_(False)
+        model.lm_head.requires_grad_(False)
+    return model

@@ -565,10 +565,13 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
     """modeling_dreamllm.py:1209-1509 (+ prompt encoding / pipeline front-end 1598-1880)."""
 
     _tied_weights_keys = {}
+    _base_model_class = None                                  # set below (DreamLLMModel); the SDXL variant swaps it
+    _dream_patch_token = DEFAULT_IMAGE_PATCH_TOKEN            # token filling the dream slots of the unconditional prompt
+    _loss_scale_twice = False                                 # the SDXL variant divides by loss_scale twice (see there)
 
     def __init__(self, config: DreamLLMConfig):
         super().__init__(config)
-        self.model = DreamLLMModel(config)
+        self.model = (self._base_model_class or DreamLLMModel)(config)
         self.vocab_size = config.vocab_size
         self.lm_head = nn.Linear(config.hidden_size, config.vocab_size, bias=False)
         self.loss_weight_lm = config.loss_weight_lm
@@ -611,6 +614,14 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
     def get_decoder(self):
         return self.model
 
+    def _head_loss(self, head, images_dm, enc, u_enc):
+        """modeling_dreamllm.py:1441."""
+        return head(images_dm, enc, u_enc)
+
+    def _head_dummy(self, head, images_dm):
+        """modeling_dreamllm.py:1445: keeps every trainable parameter in the autograd graph when a batch has no dream image."""
+        return head(images_dm, None, None, self.model.dream_embedding())
+
     def forward(self, input_ids=None, images=None, images_dm=None, attention_mask=None, position_ids=None,
                 past_key_values=None, inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
                 output_hidden_states=None, return_dict=None, dream_index=None, image_index=None, seqlens=None):
@@ -645,13 +656,13 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
                 eos_id = _special_id(self.config, DEFAULT_EOS_TOKEN, nested=False)
                 ds = _special_id(self.config, DEFAULT_DREAM_START_TOKEN)
                 de = _special_id(self.config, DEFAULT_DREAM_END_TOKEN)
-                dp = _special_id(self.config, DEFAULT_IMAGE_PATCH_TOKEN)
+                dp = _special_id(self.config, self._dream_patch_token)
                 u_ids = torch.tensor([[bos_id, ds] + [dp] * nq + [de, eos_id]], device=hidden_states.device)
                 u_out = self.model(input_ids=u_ids, attention_mask=torch.ones_like(u_ids), use_cache=False, return_dict=True)
                 u_enc = u_out.last_hidden_state[:, 2: 2 + nq, :].repeat(n_slots, 1, 1)
-            vm_loss = head(images_dm, enc, u_enc)
+            vm_loss = self._head_loss(head, images_dm, enc, u_enc)
         elif self.training and head is not None:
-            vm_loss = head(images_dm, None, None, self.model.dream_embedding())
+            vm_loss = self._head_dummy(head, images_dm)
 
         lm_loss = 0.0
         if labels is not None:
@@ -678,6 +689,8 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
         else:
             vm_term = vm_loss * self.loss_weight_vm
         loss = (vm_term + lm_term) / loss_scale
+        if self._loss_scale_twice:
+            loss = loss / loss_scale
         if not torch.is_tensor(loss):
             loss = None if labels is None and not self.training else torch.as_tensor(loss, device=hidden_states.device)
 

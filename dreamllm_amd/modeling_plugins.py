@@ -467,13 +467,13 @@ class StableDiffusionHead(MultimodalHead):
         return guidance_rescale * noise_pred_rescaled + (1 - guidance_rescale) * noise_cfg
 
     @torch.no_grad()
-    def _denoise_loop_graph(self, latents, ctx_embeds, timesteps, sched, guidance_scale):
+    def _denoise_loop_graph(self, latents, ctx_embeds, timesteps, sched, guidance_scale, added_cond_kwargs=None):
         """Deterministic-DDIM + CFG loop body (modeling_plugins.py:809-839) as: [fill t] -> hipGraph replay of one UNet
         forward on static NHWC buffers -> ONE fused kernel (CFG combine + DDIM update + next UNet input).  ~600 kernel
         launches per step collapse into one graph launch, which is what the loop is bound by at B_img = 1.  The graph
         (and its static buffers, including the cross-attention K/V of the conditioning tokens) is cached per shape."""
         B, C, H, W = latents.shape
-        key = (B, H, W, tuple(ctx_embeds.shape))
+        key = (B, H, W, tuple(ctx_embeds.shape), added_cond_kwargs is not None)
         cache = getattr(self, "_graph_cache", None)
         if cache is None:
             cache = self._graph_cache = {}
@@ -485,19 +485,26 @@ class StableDiffusionHead(MultimodalHead):
             t_dev = torch.zeros(1, dtype=torch.float32, device=dev)
             ctx_static = {k: [t.clone() for t in v] for k, v in ctx_now.items()}
             emb_static = ctx_embeds.clone()
+            # SDXL micro-conditioning (text_embeds, time_ids): static device copies read inside the captured forward
+            added_static = None if added_cond_kwargs is None else {k: v.to(dev).clone() for k, v in added_cond_kwargs.items()}
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):  # warm-up outside capture (lazy caches, kernel attributes)
                 for _ in range(2):
-                    self.unet(x_in, t_dev, emb_static, context_cache=ctx_static, nhwc_io=True, return_dict=False)
+                    self.unet(x_in, t_dev, emb_static, added_cond_kwargs=added_static, context_cache=ctx_static, nhwc_io=True,
+                              return_dict=False)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                pred = self.unet(x_in, t_dev, emb_static, context_cache=ctx_static, nhwc_io=True, return_dict=False)[0]
-            ent = cache[key] = dict(graph=graph, x_in=x_in, t=t_dev, ctx=ctx_static, pred=pred)
+                pred = self.unet(x_in, t_dev, emb_static, added_cond_kwargs=added_static, context_cache=ctx_static,
+                                 nhwc_io=True, return_dict=False)[0]
+            ent = cache[key] = dict(graph=graph, x_in=x_in, t=t_dev, ctx=ctx_static, pred=pred, added=added_static)
         for k, v in ctx_now.items():
             for dst, src in zip(ent["ctx"][k], v):
                 dst.copy_(src)
+        if added_cond_kwargs is not None:
+            for k, v in added_cond_kwargs.items():
+                ent["added"][k].copy_(v)
         lat = latents.permute(0, 2, 3, 1).contiguous().float()  # NHWC fp32 master copy
         x_in = ent["x_in"]
         x_in.zero_()

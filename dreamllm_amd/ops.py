@@ -710,22 +710,40 @@ class LMHeadCEFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hidden, weight, labels):
-        logits = linear_fwd(hidden, weight, out_dtype=torch.float32)
+        V = weight.shape[0]
+        Vp = (V + 7) // 8 * 8
+        if Vp != V:
+            # vocabulary not a multiple of 8 (DreamLLM-SDXL: 32009): the GEMMs of the backward contract over / produce the
+            # vocabulary axis and need 16-byte rows, so run the unit on a zero-padded weight; the CE kernel still sees V
+            # columns (row pitch Vp), so the pad columns enter neither the softmax nor the gradient
+            wp = torch.zeros(Vp, weight.shape[1], dtype=weight.dtype, device=weight.device)
+            wp[:V].copy_(weight)
+        else:
+            wp = weight
+        logits_p = linear_fwd(hidden, wp, out_dtype=torch.float32)
+        logits = logits_p[:, :V]
         loss_row = cross_entropy_rows(logits, labels)
         nvalid = (labels != -100).sum()
         denom = torch.clamp(nvalid, min=1).to(torch.float32)
-        ctx.save_for_backward(hidden, weight, logits, labels, denom)
+        ctx.save_for_backward(hidden, wp, logits_p, labels, denom)
+        ctx.V = V
         ctx.mark_non_differentiable(logits)
         return loss_row.sum() / denom, logits
 
     @staticmethod
     def backward(ctx, dloss, _dlogits_unused):
-        hidden, weight, logits, labels, denom = ctx.saved_tensors
+        hidden, wp, logits_p, labels, denom = ctx.saved_tensors
+        V, Vp = ctx.V, wp.shape[0]
         gscale = (dloss.to(torch.float32) / denom).reshape(1).contiguous()
-        dlogits = torch.empty(logits.shape, dtype=torch.bfloat16, device=logits.device)
-        cross_entropy_rows(logits, labels, dlogits=dlogits, gscale=gscale)
-        dh = linear_dgrad(dlogits, weight) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad(dlogits, hidden) if ctx.needs_input_grad[1] else None
+        if Vp != V:
+            dlogits_p = torch.zeros(logits_p.shape, dtype=torch.bfloat16, device=logits_p.device)
+        else:
+            dlogits_p = torch.empty(logits_p.shape, dtype=torch.bfloat16, device=logits_p.device)
+        cross_entropy_rows(logits_p[:, :V], labels, dlogits=dlogits_p[:, :V], gscale=gscale)
+        dh = linear_dgrad(dlogits_p, wp) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(dlogits_p, hidden) if ctx.needs_input_grad[1] else None
+        if dw is not None and Vp != V:
+            dw = dw[:V]
         return dh, dw, None
 
 

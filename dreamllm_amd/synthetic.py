@@ -57,3 +57,36 @@ def make_interleaved_batch(batch_size=16, seq_len=2048, images_per_sample=2, n_d
         batch["images"] = torch.randn(n_img, 3, image_size, image_size, generator=g).to(dtype).to(device)
         batch["images_dm"] = (torch.rand(n_img, 3, dm_size, dm_size, generator=g) * 2 - 1).to(dtype).to(device)
     return batch
+
+
+def make_creation_batch(batch_size=16, seq_len=256, n_dream=196, base_vocab=32000, seed=1234, device="cpu", dtype=torch.bfloat16,
+                        dm_size=1024, with_pixels=True):
+    """Creation-only batch of DreamLLM-SDXL stage I (projects/dreamllm_sdxl/configs/stage1/base.py:60-65: `creation_only`):
+    per sample `[bos] caption <dream_start> <dream_patch>*n_dream <dream_end> [eos]`, one target image per sample and its
+    six SDXL micro-conditioning numbers (original_size + crop_top_left + target_size, as `SDXLDataProcessor` returns)."""
+    from .modeling_dreamllm_sdxl import default_special_tokens2ids as sdxl_ids
+    g = torch.Generator().manual_seed(seed)
+    sp = sdxl_ids(base_vocab)
+    add = sp["additional_special_tokens"]
+    pad, bos, eos = sp["[PAD]"], sp["<s>"], sp["</s>"]
+    n_text = seq_len - (n_dream + 2) - 2
+    assert n_text >= 1, "sequence too short for the dream slot"
+    ids = torch.full((batch_size, seq_len), pad, dtype=torch.long)
+    dream_pos = []
+    for b in range(batch_size):
+        row = [bos] + torch.randint(3, base_vocab, (n_text,), generator=g).tolist()
+        dream_pos.append(b * seq_len + len(row))
+        row += [add["<dream_start>"]] + [add["<dream_patch>"]] * n_dream + [add["<dream_end>"]] + [eos]
+        ids[b] = torch.tensor(row)
+    mask = torch.ones_like(ids)
+    labels = ids.clone()
+    for t in ("<dream_patch>", "<dream_end>"):
+        labels[ids == add[t]] = -100
+    dpos = torch.tensor(dream_pos)
+    batch = dict(input_ids=ids.to(device), attention_mask=mask.to(device), labels=labels.to(device),
+                 dream_index=(dpos[:, None] + 1 + torch.arange(n_dream)[None]).reshape(-1).to(device))
+    if with_pixels:
+        batch["images_dm"] = (torch.rand(batch_size, 3, dm_size, dm_size, generator=g) * 2 - 1).to(dtype).to(device)
+        batch["add_time_ids"] = torch.tensor([[dm_size, dm_size, 0, 0, dm_size, dm_size]] * batch_size, dtype=torch.float32,
+                                             device=device)
+    return batch

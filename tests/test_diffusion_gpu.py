@@ -317,3 +317,109 @@ def test_denoise_pipeline_ddim_vs_oracle_loop():
                             negative_prompt_embeds=ne.to(DEV), output_type="latent", scheduler=DDIMScheduler())
         e = rel_l2(out, ref)
         assert e <= 1e-2 * steps**0.5 + 5e-3, (steps, e)
+
+
+# ----------------------------------------------------------------------------- SDXL head
+def _tiny_xl_head(embed=128, gdim=40):
+    from dreamllm_amd.modeling_plugins_sdxl import StableDiffusionXLHead
+    from oracle import unet_ref
+    ucfg = unet_ref.tiny_config(cross_dim=64, sdxl=True)
+    torch.manual_seed(5)
+    head = StableDiffusionXLHead(dict(unet=ucfg, vae=dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1)),
+                                 embed_hidden_size=embed, global_condition_hidden_size=gdim)
+    usd = {k: bf16r(v) for k, v in unet_ref.random_state_dict(ucfg, seed=2).items()}
+    head.unet.load_state_dict(usd)
+    for p in head.parameters():
+        p.data = bf16r(p.data)
+    return head, ucfg, usd
+
+
+def test_sdxl_head_training_loss_and_grad():
+    """StableDiffusionXLHead.forward (dreamllm_sdxl/modeling_plugins.py:151-236): mean-pooled global projector ->
+    `text_embeds`, `add_time_ids` -> SDXL UNet; loss and gradients of the dream states / both projectors vs the oracle."""
+    from oracle import unet_ref, vae_ref, sched_ref
+    head, ucfg, usd = _tiny_xl_head()
+    assert ucfg["projection_class_embeddings_input_dim"] == 40 + 6 * ucfg["addition_time_embed_dim"]
+    vsd = {k: v.clone() for k, v in head.vae.state_dict().items()}
+    pw = head.projector.projector.weight.data.clone()
+    gw = head.global_projector.projector.weight.data.clone()
+    N = 2
+    img = bf16r(torch.rand(N, 3, 128, 128) * 2 - 1)
+    enc = bf16r(torch.randn(N, 8, 128) * 0.5)
+    noise = bf16r(torch.randn(N, 4, 16, 16))
+    ts = torch.tensor([50, 800])
+    tids = torch.tensor([[128., 128, 0, 0, 128, 128], [200., 160, 8, 16, 128, 128]])
+    head = head.to(DEV, BF)
+    encd = enc.to(BF).to(DEV).requires_grad_(True)
+    torch.manual_seed(9)
+    loss = head(img.to(DEV), encd, None, tids.to(DEV), None, noise=noise.to(DEV), timesteps=ts.to(DEV))
+    loss.backward()
+    vcfg = dict(head.vae.config.to_dict())
+    mom = vae_ref.encode_moments(img, vsd, vcfg)
+    torch.manual_seed(9)
+    eps_v = torch.randn(mom[:, :4].shape, device=DEV).cpu()
+    lat = vae_ref.sample_latents(mom, eps_v, vcfg["scaling_factor"])
+    ac = sched_ref.alphas_cumprod()
+    noisy = torch.stack([sched_ref.add_noise(lat[i], noise[i], int(ts[i]), ac) for i in range(N)])
+    er = enc.clone().requires_grad_(True)
+    pwr, gwr = pw.clone().requires_grad_(True), gw.clone().requires_grad_(True)
+    added = dict(text_embeds=bf16r(F.linear(bf16r(er.mean(1)), gwr)), time_ids=tids)
+    pred = unet_ref.unet_forward(noisy, ts, F.linear(er, pwr), usd, ucfg, added_cond_kwargs=added)
+    lref = F.mse_loss(pred.float(), noise.float())
+    lref.backward()
+    assert abs(loss.item() - lref.item()) <= 2e-2 * abs(lref.item()), (loss.item(), lref.item())
+    assert rel_l2(encd.grad, er.grad) <= 6e-2
+    assert rel_l2(head.projector.projector.weight.grad, pwr.grad) <= 6e-2
+    assert rel_l2(head.global_projector.projector.weight.grad, gwr.grad) <= 8e-2
+
+
+def test_sdxl_head_dummy_forward_config_and_state_dict(tmp_path):
+    head, _, _ = _tiny_xl_head()
+    head = head.to(DEV, BF)
+    dq = torch.randn(1, 8, 128, device=DEV, dtype=BF, requires_grad=True)
+    out = head(None, None, None, None, dq)
+    out.backward()
+    assert out.item() == 0.0
+    assert head.projector.projector.weight.grad is not None and head.global_projector.projector.weight.grad is not None
+    assert set(head.config) >= {"diffusion_name_or_path", "global_condition_hidden_size", "freeze_unet", "snr_gamma"}
+    keys = set(head.state_dict())
+    assert "global_projector.projector.weight" in keys and "projector.projector.weight" in keys
+    assert not any(k.endswith("projector.bias") for k in keys)
+    head.save_model(str(tmp_path))
+    assert (tmp_path / "stable_diffusion_xl_head.bin").is_file()
+    w = head.global_projector.projector.weight.data.clone()
+    head.global_projector.projector.weight.data.zero_()
+    head.load_model(str(tmp_path))
+    assert torch.equal(head.global_projector.projector.weight.data, w)
+    assert head.fsdp_ignored_modules() == [head.vae, head.unet]
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_sdxl_pipeline_ddim_vs_oracle_loop(use_graph):
+    """StableDiffusionXLHead.pipeline (dreamllm_sdxl/modeling_plugins.py:239-445), deterministic DDIM, CFG 7.5, both the
+    hipGraph + fused-update loop and the plain loop, against the oracle loop over the oracle SDXL UNet."""
+    from dreamllm_amd.schedulers import DDIMScheduler
+    from oracle import unet_ref, sched_ref
+    head, ucfg, usd = _tiny_xl_head()
+    pw = head.projector.projector.weight.data.clone()
+    gw = head.global_projector.projector.weight.data.clone()
+    B = 2
+    pe = bf16r(torch.randn(B, 8, 128) * 0.5)
+    ne = bf16r(torch.randn(B, 8, 128) * 0.5)
+    lat0 = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(42))
+    head = head.to(DEV, BF)
+    full = ucfg["sample_size"] * 8
+    tids = torch.tensor([[float(full), full, 0, 0, full, full]] * (2 * B))
+    gl = torch.cat([bf16r(F.linear(bf16r(ne.mean(1)), gw)), bf16r(F.linear(bf16r(pe.mean(1)), gw))])
+
+    def unet_fn(x, t, c):  # the oracle loop calls it on the [uncond; cond] batch
+        return unet_ref.unet_forward(bf16r(x), torch.tensor([t]), c, usd, ucfg,
+                                     added_cond_kwargs=dict(text_embeds=gl, time_ids=tids))
+
+    for steps in (1, 4):
+        ref = sched_ref.ddim_loop(unet_fn, lat0, F.linear(ne, pw), F.linear(pe, pw), steps, 7.5)
+        out = head.pipeline(num_inference_steps=steps, guidance_scale=7.5, latents=lat0.clone(), prompt_embeds=pe.to(DEV),
+                            negative_prompt_embeds=ne.to(DEV), output_type="latent", scheduler=DDIMScheduler(),
+                            use_graph=use_graph)
+        e = rel_l2(out, ref)
+        assert e <= 1e-2 * steps**0.5 + 5e-3, (steps, e)

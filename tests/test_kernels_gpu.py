@@ -376,10 +376,11 @@ def test_adamw_matches_torch():
 
 
 # ----------------------------------------------------------------------------- autograd wrappers
-def test_linear_autograd_and_lm_head_ce():
+@pytest.mark.parametrize("V", [1000, 1009])  # 1009: vocabulary not a multiple of 8 (DreamLLM-SDXL has 32009)
+def test_linear_autograd_and_lm_head_ce(V):
     ops = _ops()
     torch.manual_seed(6)
-    T, d, V = 96, 128, 1000
+    T, d = 96, 128
     h = rnd(T, d)
     w = rnd(V, d, scale=0.05)
     labels = torch.randint(0, V, (T,))
@@ -391,6 +392,7 @@ def test_linear_autograd_and_lm_head_ce():
     loss, logits = ops.lm_head_ce(hg, wg, labels.to(DEV))
     (loss * 3.0).backward()
     assert abs(loss.item() - lref.item()) < 1e-4 * abs(lref.item()) + 1e-5
+    assert logits.shape == (T, V) and wg.grad.shape == (V, d)
     assert rel_l2(logits, (hr @ wr.t())) < 1e-5
     assert rel_l2(hg.grad, hr.grad) < 6e-3
     assert rel_l2(wg.grad, wr.grad) < 6e-3
