@@ -33,6 +33,8 @@ SIGNATURES = {
     "dllm_groupnorm_bwd": [c_void_p] * 10 + [c_int] * 5 + [c_void_p],
     "dllm_sumpool2_nhwc": [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p],
     "dllm_cfg_ddim_step": [c_void_p] * 3 + [c_i64, c_i64] + [c_float] * 5 + [c_int, c_void_p],
+    "dllm_gemv_bf16": [c_void_p] * 4 + [c_int] + [c_i64] * 6 + [c_int, c_void_p],
+    "dllm_attn_decode": [c_void_p] * 6 + [c_int] * 4 + [c_i64] * 7 + [c_float, c_int, c_void_p],
     "dllm_attn_fwd": [c_void_p] * 6 + [c_int] * 6 + [c_i64] * 9 + [c_float, c_int, c_void_p],
     "dllm_attn_bwd": [c_void_p] * 11 + [c_int] * 6 + [c_i64] * 15 + [c_float, c_int, c_void_p],
     "dllm_rope": [c_void_p] * 4 + [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void_p],
@@ -56,7 +58,8 @@ SIGNATURES = {
 }
 
 # functions whose return type is not int
-RESTYPES = {"dllm_groupnorm_ws_floats": (c_i64, [c_int, c_int, c_int])}
+RESTYPES = {"dllm_groupnorm_ws_floats": (c_i64, [c_int, c_int, c_int]),
+            "dllm_attn_decode_ws_floats": (c_i64, [c_int, c_int, c_int, c_int])}
 
 _lib = None
 

@@ -1,0 +1,129 @@
+"""KV-cache greedy decoding of DreamLLMForCausalMLM on the HIP decode kernels, one hipGraph replay per token.
+
+Reference loop: omni/eval/language_eval/modeling_dreamllm.py:76-97 with temperature 0 (argmax, :92) over
+DreamLLMForCausalMLM.forward (modeling_dreamllm.py:1353) with `use_cache=True`.  The reference re-enters the whole Python model
+per token (~15 kernels x 32 layers + host logic); at batch 1 that is launch-bound by an order of magnitude over the weight
+stream.  Here the token step is a fixed sequence of launches on static buffers:
+
+    embed[tok] -> 32 x { RMSNorm -> q/k/v GEMV -> RoPE(pos on device) -> K/V appended to the cache at pos (index_copy on a
+    device index) -> decode attention over the cache (valid length on device) -> o GEMV + residual -> RMSNorm -> gate/up GEMV ->
+    SwiGLU -> down GEMV + residual } -> final RMSNorm -> lm_head GEMV (fp32 logits) -> argmax -> pos/len/step += 1
+
+captured once per (batch, max_len) in a hipGraph (`torch.cuda.CUDAGraph`) and replayed per token; nothing in it depends on the
+host.  Prefill runs through the normal model forward (MFMA GEMMs + flash attention) and its K/V are copied into the cache.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+
+
+class GreedyDecodeSession:
+    def __init__(self, model, batch_size: int, max_len: int, use_graph: bool = True, nsplit: int = 8):
+        cfg = model.config
+        self.model = model
+        self.B, self.max_len, self.use_graph, self.nsplit = batch_size, max_len, use_graph, nsplit
+        if batch_size > 8:
+            raise ValueError("the decode GEMV handles up to 8 sequences per step")
+        dev, dt = model.device, model.dtype
+        self.H, self.Hkv = cfg.num_attention_heads, cfg.num_key_value_heads
+        self.D = cfg.hidden_size // self.H
+        L = cfg.num_hidden_layers
+        self.kc = [torch.zeros(batch_size, max_len, self.Hkv, self.D, dtype=dt, device=dev) for _ in range(L)]
+        self.vc = [torch.zeros(batch_size, max_len, self.Hkv, self.D, dtype=dt, device=dev) for _ in range(L)]
+        self.tok = torch.zeros(batch_size, dtype=torch.long, device=dev)          # token fed to the next step
+        self.pos = torch.zeros(batch_size, 1, dtype=torch.long, device=dev)       # its position id
+        self.kv_len = torch.zeros(batch_size, dtype=torch.int32, device=dev)      # valid cache length INCLUDING that token
+        self.slot = torch.zeros(batch_size, dtype=torch.long, device=dev)         # row of cache.view(B*max_len, -1) to write
+        self.step_idx = torch.zeros(1, dtype=torch.long, device=dev)
+        self.out_tokens = torch.zeros(max_len, batch_size, dtype=torch.long, device=dev)
+        rope = model.model.layers[0].self_attn.rotary_emb
+        self.cos, self.sin = rope.tables(max_len, dev)
+        self.graph = None
+        self.logits = None
+
+    # ---- one token -------------------------------------------------------------------------------------------------
+    def _token_step(self):
+        m = self.model
+        cfg = m.config
+        B, H, Hkv, D = self.B, self.H, self.Hkv, self.D
+        eps = cfg.rms_norm_eps
+        x = m.model.embed_tokens.weight.index_select(0, self.tok)  # [B, d]
+        for li, layer in enumerate(m.model.layers):
+            at, mlp = layer.self_attn, layer.mlp
+            h, _, _ = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, eps)
+            q = ops.gemv(h, at.q_proj.weight).view(B, 1, H, D)
+            k = ops.gemv(h, at.k_proj.weight).view(B, 1, Hkv, D)
+            v = ops.gemv(h, at.v_proj.weight)
+            ops.rope_(q, self.cos, self.sin, self.pos)
+            ops.rope_(k, self.cos, self.sin, self.pos)
+            self.kc[li].view(B * self.max_len, Hkv * D).index_copy_(0, self.slot, k.view(B, Hkv * D))
+            self.vc[li].view(B * self.max_len, Hkv * D).index_copy_(0, self.slot, v)
+            o = ops.attn_decode(q.view(B, H, D), self.kc[li], self.vc[li], self.kv_len, 1.0 / math.sqrt(D), self.nsplit)
+            x2 = ops.gemv(o.view(B, H * D), at.o_proj.weight, residual=x)
+            h2, _, _ = ops.rmsnorm_fwd(x2, layer.post_attention_layernorm.weight, eps)
+            g = ops.gemv(h2, mlp.gate_proj.weight)
+            u = ops.gemv(h2, mlp.up_proj.weight)
+            x = ops.gemv(ops.glu_fwd(g, u, 0), mlp.down_proj.weight, residual=x2)
+        hf, _, _ = ops.rmsnorm_fwd(x, m.model.norm.weight, eps)
+        logits = ops.gemv(hf, m.lm_head.weight, out_dtype=torch.float32)
+        nxt = logits.argmax(-1)
+        self.out_tokens.index_copy_(0, self.step_idx, nxt[None])
+        self.tok.copy_(nxt)
+        self.pos.add_(1)
+        self.kv_len.add_(1)
+        self.slot.add_(1)
+        self.step_idx.add_(1)
+        return logits
+
+    # ---- public ----------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def prefill(self, input_ids, images=None, attention_mask=None):
+        """Run the prompt through the model (MFMA path), fill the cache, emit the first new token."""
+        B, S = input_ids.shape
+        if B != self.B or S >= self.max_len:
+            raise ValueError(f"prompt [{B},{S}] does not fit the session (batch {self.B}, max_len {self.max_len})")
+        out = self.model(input_ids=input_ids, images=images, attention_mask=attention_mask, use_cache=True, return_dict=True)
+        for li, (k, v) in enumerate(out.past_key_values):  # reference layout [B, Hkv, S, D]
+            self.kc[li][:, :S].copy_(k.transpose(1, 2))
+            self.vc[li][:, :S].copy_(v.transpose(1, 2))
+        first = out.logits[:, -1].argmax(-1)
+        self.tok.copy_(first)
+        self.pos.fill_(S)
+        self.kv_len.fill_(S + 1)
+        self.slot.copy_(torch.arange(B, device=self.tok.device) * self.max_len + S)
+        self.step_idx.zero_()
+        self.prompt_len = S
+        self.first = first
+        return first
+
+    @torch.no_grad()
+    def generate(self, n_more: int):
+        """n_more further tokens after the one `prefill` produced; returns [B, n_more]."""
+        if self.prompt_len + 1 + n_more > self.max_len:
+            raise ValueError("generation would overflow the KV cache")
+        if n_more <= 0:
+            return self.out_tokens[:0].t()
+        if self.use_graph and self.graph is None:
+            state = [t.clone() for t in (self.tok, self.pos, self.kv_len, self.slot, self.step_idx)]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up outside capture
+                self._token_step()
+            torch.cuda.current_stream().wait_stream(side)
+            for t, s in zip((self.tok, self.pos, self.kv_len, self.slot, self.step_idx), state):
+                t.copy_(s)  # the warm-up wrote cache row `slot`, which the first real step rewrites identically
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.logits = self._token_step()
+            for t, s in zip((self.tok, self.pos, self.kv_len, self.slot, self.step_idx), state):
+                t.copy_(s)  # capture does not execute, but keep the state explicit
+        for _ in range(n_more):
+            if self.use_graph:
+                self.graph.replay()
+            else:
+                self.logits = self._token_step()
+        return self.out_tokens[:n_more].t().contiguous()

@@ -726,9 +726,25 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
         return model_inputs
 
     @torch.no_grad()
-    def greedy_generate(self, input_ids, max_new_tokens, images=None):
+    def greedy_generate(self, input_ids, max_new_tokens, images=None, fast=None, use_graph=True):
         """Greedy decode with a KV cache: the loop of omni/eval/language_eval/modeling_dreamllm.py:76-97 with
-        temperature == 0 (argmax, :92)."""
+        temperature == 0 (argmax, :92).  `fast` (default: batch <= 8) runs the token steps on the decode kernels
+        (GEMV + cache attention, one hipGraph replay per token: `decode.GreedyDecodeSession`); `fast=False` re-enters the model
+        forward per token like the reference loop does."""
+        B, S = input_ids.shape
+        if fast is None:
+            fast = B <= 8
+        if fast:
+            from .decode import GreedyDecodeSession
+            key = (B, S + max_new_tokens + 1, use_graph)
+            sess = getattr(self, "_decode_session", None)
+            if sess is None or sess[0] != key:
+                sess = (key, GreedyDecodeSession(self, B, key[1], use_graph=use_graph))
+                self._decode_session = sess
+            sess = sess[1]
+            first = sess.prefill(input_ids, images=images)
+            rest = sess.generate(max_new_tokens - 1)
+            return torch.cat([input_ids, first[:, None], rest], dim=1)
         out = self(input_ids=input_ids, images=images, use_cache=True, return_dict=True)
         past = out.past_key_values
         tokens = [out.logits[:, -1].argmax(-1)]

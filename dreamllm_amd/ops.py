@@ -1015,3 +1015,46 @@ def geglu_packed(h):
 
 def swiglu_packed(h):
     return PackedGLUFn.apply(h, 0)
+
+
+# --------------------------------------------------------------------------------------------- greedy-decode operators
+def gemv(x, w, residual=None, out_dtype=torch.bfloat16, out=None):
+    """y[M,N] = x[M,K] w[N,K]^T (+ residual), M <= 8: the HBM-bound decode form of nn.Linear (one wave per output row)."""
+    _need_gpu(x, w, residual)
+    _bf16(x, w, residual)
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M, K = x2.shape
+    N = w.shape[0]
+    wc = w if w.is_contiguous() else w.contiguous()
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, N)
+        if r2.stride(-1) != 1:
+            r2 = r2.contiguous()
+    if out is None:
+        out = torch.empty(M, N, dtype=out_dtype, device=x.device)
+    check("dllm_gemv_bf16", _p(x2), _p(wc), _p(out), _p(r2), M, N, K, x2.stride(0), K, out.stride(0),
+          r2.stride(0) if r2 is not None else 0, _dt(out), _stream())
+    return out
+
+
+def attn_decode(q, kcache, vcache, kv_len, scale=None, nsplit=8, out=None):
+    """q [B,H,D]; kcache/vcache [B,Smax,Hkv,D] (same strides); kv_len int32 [B] ON DEVICE (valid cache length, read by the
+    kernel: the launch does not depend on it) -> [B,H,D]."""
+    _need_gpu(q, kcache, vcache, kv_len)
+    _bf16(q, kcache, vcache)
+    B, H, D = q.shape
+    Hkv = kcache.shape[2]
+    if kcache.stride() != vcache.stride() or kcache.stride(3) != 1 or q.stride(2) != 1:
+        raise ValueError("attn_decode: k/v caches must share strides; head dim contiguous")
+    if kv_len.dtype != torch.int32:
+        raise TypeError("attn_decode: kv_len must be int32")
+    if out is None:
+        out = torch.empty(B, H, D, dtype=q.dtype, device=q.device)
+    ws = torch.empty(_lib.lib().dllm_attn_decode_ws_floats(B, H, D, nsplit), dtype=torch.float32, device=q.device)
+    check("dllm_attn_decode", _p(q), _p(kcache), _p(vcache), _p(kv_len), _p(out), _p(ws), B, H, Hkv, D, q.stride(0), q.stride(1),
+          kcache.stride(0), kcache.stride(1), kcache.stride(2), out.stride(0), out.stride(1),
+          float(scale if scale is not None else D ** -0.5), nsplit, _stream())
+    return out

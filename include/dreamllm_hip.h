@@ -163,6 +163,20 @@ int dllm_reduce_sum_f32(const float* in, int64_t n, float* out, void* stream);  
 int dllm_cfg_ddim_step(const void* pred, float* latents, void* next_in, int64_t n_half, int64_t unused, float guidance,
                        float sqrt_at, float sqrt_1mat, float sqrt_aprev, float sqrt_1maprev, int v_prediction, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------- greedy decode
+ * Token step of the KV-cache decode loop (omni/eval/language_eval/modeling_dreamllm.py:76-97): every nn.Linear of
+ * modeling_dreamllm.py:212-239,254-400,1452 degenerates to y[M<=8][N] = x W^T, HBM-bound on W.
+ * dllm_gemv_bf16: one wave per output row, fp32 accumulate, optional fused residual, bf16 or fp32 (logits) output.
+ * dllm_attn_decode: softmax(q K^T * scale) V for ONE query token per (b, h) over the cache [B][S_max][Hkv][D]; the valid
+ * length kv_len[b] is read from device memory so that the launch is step-invariant (hipGraph replay).  ws: fp32 workspace of
+ * dllm_attn_decode_ws_floats(B, H, D, nsplit) elements (split-KV partial softmax states). */
+int dllm_gemv_bf16(const void* x, const void* W, void* y, const void* residual, int M, int64_t N, int64_t K, int64_t ldx,
+                   int64_t ldw, int64_t ldy, int64_t ldr, int out_dtype, void* stream);
+int64_t dllm_attn_decode_ws_floats(int B, int H, int D, int nsplit);
+int dllm_attn_decode(const void* q, const void* kcache, const void* vcache, const int* kv_len, void* out, float* ws, int B, int H,
+                     int Hkv, int D, int64_t q_sb, int64_t q_sh, int64_t c_sb, int64_t c_ss, int64_t c_sh, int64_t o_sb,
+                     int64_t o_sh, float scale, int nsplit, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------- test probes
  * hardware-convention probes used by tests/test_kernels_gpu.py (ds_read_b64_tr_b16 and MFMA 16x16x32 fragment layouts) */
 int dllm_probe_tr16(const void* in256, void* out256, void* stream);

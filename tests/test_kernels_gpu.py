@@ -482,3 +482,36 @@ def test_gemm_splitk_small_grid(M, N, K):
     assert rel_l2(dw, dy.float().t() @ xx.float()) < 1e-5
     dx = ops.linear_dgrad(rnd(M, K).to(DEV) * 0 + x.to(DEV), rnd(K, N, seed=1).to(DEV))
     assert rel_l2(dx, x.float() @ rnd(K, N, seed=1).float()) < 4e-3
+
+
+# ----------------------------------------------------------------------------- greedy-decode kernels
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (1, 11008, 4096), (3, 1000, 11008), (8, 515, 128), (2, 32008, 512)])
+@pytest.mark.parametrize("f32", [False, True])
+def test_gemv(M, N, K, f32):
+    ops = _ops()
+    x, w, r = rnd(M, K, seed=M + N), rnd(N, K, scale=0.05), rnd(M, N)
+    ref = x.float() @ w.float().t() + r.float()
+    y = ops.gemv(x.to(DEV), w.to(DEV), residual=r.to(DEV), out_dtype=torch.float32 if f32 else BF)
+    assert y.dtype == (torch.float32 if f32 else BF) and y.shape == (M, N)
+    assert rel_l2(y, ref) < (2e-5 if f32 else 4e-3)
+    y2 = ops.gemv(x.to(DEV), w.to(DEV), out_dtype=torch.float32)
+    assert rel_l2(y2, x.float() @ w.float().t()) < 2e-5
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,Smax,lens,nsplit", [
+    (1, 32, 32, 128, 2048, [1500], 8), (3, 4, 4, 128, 300, [1, 300, 57], 8), (2, 6, 2, 64, 200, [200, 13], 4),
+    (2, 4, 4, 128, 64, [5, 64], 1), (1, 2, 1, 64, 40, [3], 16)])
+def test_attn_decode(B, H, Hkv, D, Smax, lens, nsplit):
+    """One query token against a KV cache whose valid length lives on the device (entries past it hold garbage)."""
+    ops = _ops()
+    q, kc, vc = rnd(B, H, D, seed=B + H), rnd(B, Smax, Hkv, D), rnd(B, Smax, Hkv, D)
+    for b, n in enumerate(lens):
+        kc[b, n:] = 1e4  # must never be read into the softmax
+        vc[b, n:] = 1e4
+    out = ops.attn_decode(q.to(DEV), kc.to(DEV), vc.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), nsplit=nsplit)
+    for b, n in enumerate(lens):
+        k = kc[b, :n].float().repeat_interleave(H // Hkv, dim=1)  # [n, H, D]
+        v = vc[b, :n].float().repeat_interleave(H // Hkv, dim=1)
+        p = torch.softmax(torch.einsum("hd,nhd->hn", q[b].float(), k) * D ** -0.5, dim=-1)
+        ref = torch.einsum("hn,nhd->hd", p, v)
+        assert rel_l2(out[b], ref) < 6e-3, (b, n)

@@ -171,14 +171,47 @@ def test_causal_mlm_fast_index_path_matches(golden):
     assert torch.equal(a.logits, b.logits) and torch.equal(a.loss, b.loss)
 
 
-def test_greedy_decode_golden(golden):
-    """BASELINE config 1 plumbing: KV-cache prefill + 8 greedy steps reproduce the reference's token ids."""
+@pytest.mark.parametrize("mode", ["graph", "kernels", "model"])
+def test_greedy_decode_golden(golden, mode):
+    """BASELINE config 1 plumbing: KV-cache prefill + 8 greedy steps reproduce the reference's token ids -- through the
+    decode kernels replayed as a hipGraph ("graph"), the same kernels launched eagerly ("kernels"), and the per-token model
+    forward ("model")."""
     g = golden("causal_mlm.pt")
     gd = golden("greedy_decode.pt")
     lm = _build_lm(g).eval()
-    toks = lm.greedy_generate(gd["prompt"].to(DEV), 8)
+    toks = lm.greedy_generate(gd["prompt"].to(DEV), 8, fast=mode != "model", use_graph=mode == "graph")
     # bf16 logits can flip an argmax only on near-ties; require the reference sequence (seeded, no ties in the fixture)
     assert torch.equal(toks.cpu(), gd["tokens"]), (toks.cpu(), gd["tokens"])
+
+
+def test_decode_session_matches_model_forward_logits():
+    """Token-step logits of GreedyDecodeSession (GEMV + cache attention, hipGraph replay) against a full model forward over
+    the same prefix, batch 3, for 6 consecutive steps (teacher-forced on the session's own tokens, so near-ties of the
+    random-weight logits cannot make the two paths diverge); a second `prefill` on the same session reproduces the run."""
+    from dreamllm_amd.decode import GreedyDecodeSession
+    from dreamllm_amd.factory import TINY, build_dreamllm
+    lm = build_dreamllm(TINY, device=DEV, dtype=BF, with_clip=False, with_sd=False).eval()
+    torch.manual_seed(3)
+    ids = torch.randint(3, 30000, (3, 21), device=DEV)
+    sess = GreedyDecodeSession(lm, 3, 64, use_graph=True)
+    first = sess.prefill(ids)
+    seq = torch.cat([ids, first[:, None]], 1)
+    toks = []
+    for _ in range(6):
+        nxt = sess.generate(1)  # NB: out_tokens row 0 is rewritten per call only after a new prefill; read the logits
+        with torch.no_grad():
+            full = lm(input_ids=seq, return_dict=True).logits[:, -1]
+        assert rel_l2(sess.logits, full) < 2e-2
+        tok = sess.logits.argmax(-1)
+        top2 = full.float().topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 0.05
+        assert torch.equal(tok[clear], full.argmax(-1)[clear])
+        toks.append(tok)
+        seq = torch.cat([seq, tok[:, None]], 1)
+    assert torch.equal(sess.out_tokens[:6].t(), torch.stack(toks, 1))
+    first2 = sess.prefill(ids)
+    rest2 = sess.generate(6)
+    assert torch.equal(first2, first) and torch.equal(rest2, torch.stack(toks, 1))
 
 
 def test_projectors_golden(golden):
