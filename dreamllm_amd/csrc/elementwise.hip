@@ -232,17 +232,38 @@ __global__ __launch_bounds__(256) void adamw_kernel(PT* __restrict__ p, const PT
     }
 }
 
-// sum of squares of a bf16/fp32 buffer into a fp32 accumulator (grad-norm clipping); atomicAdd of per-block partials.
+// sum of squares of a bf16/fp32 buffer (grad-norm clipping) as one partial per block: no atomics => bit-identical on every
+// DDP replica.  HBM-bound (2 B/elt): 1024-thread blocks, 16-byte loads, 4 of them in flight per thread (64 KiB per CU).
 template <typename T>
-__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, int64_t n, float* __restrict__ out) {
-    __shared__ float scratch[4];
+__global__ __launch_bounds__(1024) void sumsq_kernel(const T* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float scratch[16];
+    constexpr int VE = 16 / (int)sizeof(T);  // elements per 16-byte vector
+    typedef T vec_t __attribute__((ext_vector_type(VE)));
     float s = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float v = (float)x[i];
+    const bool aligned = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const int64_t nv = aligned ? n / VE : 0;
+    const vec_t* xv = reinterpret_cast<const vec_t*>(x);
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    for (; i + 3 * stride < nv; i += 4 * stride) {
+        const vec_t a = xv[i], b = xv[i + stride], c = xv[i + 2 * stride], d = xv[i + 3 * stride];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            const float fa = (float)a[e], fb = (float)b[e], fc = (float)c[e], fd = (float)d[e];
+            s += fa * fa + fb * fb + fc * fc + fd * fd;
+        }
+    }
+    for (; i < nv; i += stride) {
+        const vec_t a = xv[i];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) s += (float)a[e] * (float)a[e];
+    }
+    for (int64_t j = nv * VE + (int64_t)blockIdx.x * 1024 + threadIdx.x; j < n; j += stride) {  // tail / unaligned buffer
+        const float v = (float)x[j];
         s += v * v;
     }
-    s = block_sum<4>(s, scratch);
-    if (threadIdx.x == 0) out[blockIdx.x] = s;  // per-block partial: no atomics => bit-identical on every DDP replica
+    s = block_sum<16>(s, scratch);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
 }
 
 // out[0] = sum(in[0..n)) in a fixed order (single block): final stage of the deterministic reductions
@@ -505,12 +526,12 @@ int dllm_adamw(void* p, const void* g, void* m, void* v, int64_t n, int param_dt
 int dllm_sumsq(const void* x, int64_t n, int dtype, float* out, void* stream) {
     if (n < 0) return DLLM_ERR_SHAPE;
     if (n == 0) return DLLM_OK;
-    int g = grid_for(n);
+    int64_t g = cdiv64(n, 8 * 1024);
     if (g > 256) g = 256;
     if (dtype == DLLM_BF16)
-        hipLaunchKernelGGL(sumsq_kernel<bf16>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, n, out);
+        hipLaunchKernelGGL(sumsq_kernel<bf16>, dim3((unsigned)g), dim3(1024), 0, (hipStream_t)stream, (const bf16*)x, n, out);
     else if (dtype == DLLM_F32)
-        hipLaunchKernelGGL(sumsq_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, n, out);
+        hipLaunchKernelGGL(sumsq_kernel<float>, dim3((unsigned)g), dim3(1024), 0, (hipStream_t)stream, (const float*)x, n, out);
     else
         return DLLM_ERR_DTYPE;
     return dllm_check_launch();

@@ -145,6 +145,72 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16* __restrict
     }
 }
 
+// Block-per-row variant for D = 2048 * VPL (the LLM's 4096): a row is spread over the 4 waves of a block (VPL 16-byte vectors
+// per lane instead of 8), so the kernel needs ~70 VGPRs instead of 256 and runs 8 blocks per CU -- the wave-per-row kernel above
+// holds 4 rows of fp32 state per lane and is limited to one wave per SIMD (2.1 TB/s).  dw_partial row = blockIdx.x.
+template <int VPL>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_block_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ h,
+                                                                const bf16* __restrict__ w, const float* __restrict__ rstd_in,
+                                                                const bf16* __restrict__ dh_in, bf16* __restrict__ dx,
+                                                                float* __restrict__ dw_partial, int64_t rows, int D) {
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float wv[VPL][8], acc[VPL][8];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const bf16x8 t = ld_bf16x8(w + (int64_t)(tid + 256 * i) * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            wv[i][j] = (float)t[j];
+            acc[i][j] = 0.f;
+        }
+    }
+    int par = 0;
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
+        float g[VPL][8], xh[VPL][8];
+        const float rstd = rstd_in[row];
+        float c = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const bf16x8 a = ld_bf16x8(dy + row * D + (int64_t)(tid + 256 * i) * 8);
+            const bf16x8 b = ld_bf16x8(h + row * D + (int64_t)(tid + 256 * i) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                xh[i][j] = (float)b[j] * rstd;
+                if (dw_partial != nullptr) acc[i][j] += (float)a[j] * xh[i][j];
+                g[i][j] = (float)a[j] * wv[i][j];
+                c += g[i][j] * xh[i][j];
+            }
+        }
+        c = wave_sum(c);
+        if (lane == 0) red[par][wave] = c;  // two slots: the next row's write cannot race this row's reads
+        __syncthreads();
+        c = (red[par][0] + red[par][1] + red[par][2] + red[par][3]) / (float)D;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int64_t off = row * D + (int64_t)(tid + 256 * i) * 8;
+            bf16x8 o;
+            if (dh_in != nullptr) {
+                const bf16x8 d = ld_bf16x8(dh_in + off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)(rstd * (g[i][j] - xh[i][j] * c) + (float)d[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)(rstd * (g[i][j] - xh[i][j] * c));
+            }
+            st_bf16x8(dx + off, o);
+        }
+    }
+    if (dw_partial != nullptr) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float* p = dw_partial + (int64_t)blockIdx.x * D + (int64_t)(tid + 256 * i) * 8;
+            *reinterpret_cast<f32x4*>(p) = f32x4{acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+            *reinterpret_cast<f32x4*>(p + 4) = f32x4{acc[i][4], acc[i][5], acc[i][6], acc[i][7]};
+        }
+    }
+}
+
 // out[c] = sum_p partial[p][c]; 64 columns per block, 4 row groups reduced through LDS.
 __global__ __launch_bounds__(256) void colsum_partials_kernel(const float* __restrict__ partial, void* __restrict__ out,
                                                               int nparts, int D, int out_dtype) {
@@ -310,7 +376,7 @@ extern "C" {
 // Number of fp32 partial rows the backward kernels write (workspace = nparts * D floats).
 int dllm_norm_bwd_nparts(int64_t rows) {
     int64_t blocks = (rows + 3) / 4;
-    if (blocks > 256) blocks = 256;
+    if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     return (int)(blocks * 4);
 }
@@ -335,9 +401,21 @@ int dllm_rmsnorm_bwd(const void* dy, const void* h, const void* w, const float* 
     if (rows == 0) return DLLM_OK;
     const int nparts = dllm_norm_bwd_nparts(rows);
     dim3 grid(nparts / 4), block(256);
-    DISPATCH_MAXV(mv, rmsnorm_bwd_kernel, grid, block, stream, (const bf16*)dy,
-                                          (const bf16*)h, (const bf16*)w, rstd, (const bf16*)dh_in, (bf16*)dx, dw_partial,
-                                          rows, D);
+    if ((D % 2048) == 0 && D <= 8192) {  // block per row: one partial row per block, nparts blocks
+        const dim3 g2(nparts);
+        hipStream_t s = (hipStream_t)stream;
+        const bf16 *dyp = (const bf16*)dy, *hp = (const bf16*)h, *wp = (const bf16*)w, *dhp = (const bf16*)dh_in;
+        switch (D / 2048) {
+            case 1: hipLaunchKernelGGL(rmsnorm_bwd_block_kernel<1>, g2, block, 0, s, dyp, hp, wp, rstd, dhp, (bf16*)dx, dw_partial, rows, D); break;
+            case 2: hipLaunchKernelGGL(rmsnorm_bwd_block_kernel<2>, g2, block, 0, s, dyp, hp, wp, rstd, dhp, (bf16*)dx, dw_partial, rows, D); break;
+            case 3: hipLaunchKernelGGL(rmsnorm_bwd_block_kernel<3>, g2, block, 0, s, dyp, hp, wp, rstd, dhp, (bf16*)dx, dw_partial, rows, D); break;
+            default: hipLaunchKernelGGL(rmsnorm_bwd_block_kernel<4>, g2, block, 0, s, dyp, hp, wp, rstd, dhp, (bf16*)dx, dw_partial, rows, D); break;
+        }
+    } else {
+        DISPATCH_MAXV(mv, rmsnorm_bwd_kernel, grid, block, stream, (const bf16*)dy,
+                                              (const bf16*)h, (const bf16*)w, rstd, (const bf16*)dh_in, (bf16*)dx, dw_partial,
+                                              rows, D);
+    }
     if (dw_partial != nullptr && dw_out != nullptr) {
         hipLaunchKernelGGL(colsum_partials_kernel, dim3((D + 63) / 64), dim3(256), 0, (hipStream_t)stream, dw_partial, dw_out,
                            nparts, D, dw_dtype);
