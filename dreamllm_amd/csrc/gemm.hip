@@ -312,6 +312,7 @@ template <int MI>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[MI][4], int64_t mbase, int64_t nbase, int lane,
                                               int split = 0) {
     const bool vec_ok = ((P.N & 3) == 0) && ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
+    if (P.dbg_noload == 3 && acc[0][0][0] != 12345.678f) return;  // benchmark-only: no C stores (the test keeps acc live)
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int64_t m = mbase + i * 16 + (lane & 15);
@@ -328,6 +329,84 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * P.alpha;
             epilogue_store4(P, m, n, v, vec_ok);
+        }
+    }
+}
+
+// ---- LDS-staged epilogue for full, 16-byte-aligned bf16 output tiles (wave tile 128 x 64) ------------------------------------
+// The direct epilogue above stores 8 bytes per lane: one store instruction touches 16 rows x 32 bytes, and four instructions
+// are needed to complete a 128-byte line.  Measured on the 256-tile kernels that costs ~20 us per output tile (268 MB of C at
+// 1.6 TB/s; tools/gemm_ksweep.py with and without the stores).  Here each wave passes its tile through a private 8-KiB LDS
+// region in two 64-row halves: ds_write_b64 in the accumulator layout (XOR-swizzled: chunk ^ 2*((row>>1)&7), conflict-free
+// for the 16-lane write groups), ds_read_b128 row-contiguous, then 16-byte global stores of 8 rows x 128 contiguous bytes.
+// Bias / activation / residual / accumulate are applied before the LDS write (single rounding, as in the direct epilogue).
+__device__ __forceinline__ bool epilogue_lds_ok(const GemmParams& P, int64_t m0, int64_t n0, int T) {
+    return !P.out_f32 && P.splitk <= 1 && P.dbg_noload != 3 && (P.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(P.C) & 15) == 0 &&
+           m0 + T <= P.M && n0 + T <= P.N && (P.residual == nullptr || (P.ldr & 3) == 0);
+}
+__device__ __forceinline__ void epilogue_values4(const GemmParams& P, int64_t m, int64_t n, float (&v)[4]) {
+    if (P.bias != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)P.bias[n + r];
+    }
+    if (P.rg_bias != nullptr) {
+        const bf16* rb = P.rg_bias + (m / P.rg_rows) * P.N + n;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rb[r];
+    }
+    if (P.epi == EPI_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+    } else if (P.epi == EPI_QUICK_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
+    } else if (P.epi == EPI_SILU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+    }
+    if (P.residual != nullptr) {
+        const bf16x4 rv = ld_bf16x4(P.residual + m * P.ldr + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+    }
+    if (P.accumulate) {
+        const bf16x4 c = ld_bf16x4(reinterpret_cast<const bf16*>(P.C) + m * P.ldc + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)c[r];
+    }
+}
+// wl: this wave's private 8-KiB LDS region (64 rows x 128 bytes); (mw, nw): global origin of the wave's (16 MI) x 64 tile
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& P, f32x4 (&acc)[MI][4], char* wl, int64_t mw, int64_t nw,
+                                                  int lane) {
+    const bool plain = P.bias == nullptr && P.rg_bias == nullptr && P.epi == 0 && P.residual == nullptr && !P.accumulate;
+    bf16* C = reinterpret_cast<bf16*>(P.C);
+#pragma unroll
+    for (int half = 0; half < MI / 4; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = half * 4 + ii;
+            const int r = ii * 16 + (lane & 15);
+            const int sw = ((r >> 1) & 7) << 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * P.alpha;
+                if (!plain) epilogue_values4(P, mw + i * 16 + (lane & 15), nw + j * 16 + (lane >> 4) * 4, v);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                const int q = (j * 4 + (lane >> 4)) ^ sw;
+                *reinterpret_cast<bf16x4*>(wl + r * 128 + q * 8) = o;
+            }
+        }
+        // wave-private region: only this wave's own LDS traffic has to be ordered (the compiler inserts the lgkmcnt waits)
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3), p = lane & 7;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(wl + row * 128 + ((p ^ ((row >> 1) & 7)) << 4));
+            st_bf16x8(C + (mw + half * 64 + row) * P.ldc + nw + p * 8, v);
         }
     }
 }
@@ -456,7 +535,10 @@ __global__ __launch_bounds__(2 * T, 2) void gemm_bf16_kernel(GemmParams P) {
         __syncthreads();
     }
 
-    gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane, blockIdx.y);
+    if (epilogue_lds_ok(P, m0, n0, T))  // the loop ended on a barrier: the stages are free to serve as per-wave staging regions
+        gemm_epilogue_lds<MI>(P, acc, smem + wave * 8192, m0 + wm, n0 + wn, lane);
+    else
+        gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane, blockIdx.y);
 }
 
 
@@ -830,7 +912,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
             __builtin_amdgcn_sched_barrier(0);
         });
     }
-    gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane);
+    if (epilogue_lds_ok(P, m0, n0, T)) {
+        // every wave must be done with its fragment reads before the stages are reused as per-wave staging regions
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        gemm_epilogue_lds<MI>(P, acc, smem + wave * 8192, m0 + wm, n0 + wn, lane);
+    } else {
+        gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane);
+    }
 }
 
 template <int AL, int BL, int T>
@@ -966,10 +1055,11 @@ int dllm_gemm_set_tile(int tile) {
     // 258: like 257 but WITHOUT the K-loop prefetches (wrong results; exposes the compute+barrier ceiling in microbenchmarks)
     // 259: 257 with the software-pipelined kernel; 260: 259 without the K-loop prefetches (benchmark only)
     // 263: 259 with every prefetch reading K tile 0 (wrong results; all loads hit in L2: isolates the DMA path from HBM/L2 misses)
-    if (tile != 0 && tile != 128 && (tile < 256 || tile > 260) && tile != 263) return DLLM_ERR_SHAPE;
+    // 265: 259 without the C stores (benchmark only)
+    if (tile != 0 && tile != 128 && (tile < 256 || tile > 260) && tile != 263 && tile != 265) return DLLM_ERR_SHAPE;
     g_use_glds = (tile == 0 || tile >= 257);
-    g_glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 263);
-    g_dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : 0);
+    g_glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 263 || tile == 265);
+    g_dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
     g_force_tile = tile >= 257 ? 256 : tile;
     return DLLM_OK;
 }

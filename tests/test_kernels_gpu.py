@@ -194,6 +194,35 @@ def test_gemm_epilogues(epi, gemm_tile):
     assert rel_l2(y, ref) < 4e-3
 
 
+@pytest.mark.parametrize("variant", ["plain", "bias_act_res", "accumulate_alpha"])
+def test_gemm_full_tile_epilogue_and_persistent_walk(variant, gemm_tile):
+    """5888 x 5888 outputs = 23 x 23 full 256-tiles (529 >= 2 x 256 CUs: the persistent walk of tile mode 264 engages, and the
+    256-tile kernels take the LDS-staged epilogue on every tile), K = 192 = 3 K tiles (odd: the LDS stage parity flips between
+    consecutive output tiles), with the epilogue variants the LLM uses."""
+    ops = _ops()
+    torch.manual_seed(11)
+    M = N = 5888
+    K = 192
+    x, w = rnd(M, K), rnd(N, K, scale=0.05)
+    ref = x.float() @ w.float().t()
+    xd, wd = x.to(DEV), w.to(DEV)
+    if variant == "plain":
+        y = ops.linear_fwd(xd, wd)
+    elif variant == "bias_act_res":
+        b, r = rnd(N), rnd(M, N)
+        ref = F.silu(ref + b.float()) + r.float()
+        y = ops.linear_fwd(xd, wd, bias=b.to(DEV), epi="silu", residual=r.to(DEV))
+    else:
+        c0 = rnd(M, N)
+        y = c0.to(DEV).clone()
+        ops.gemm(xd, wd, M, N, K, K, K, 0, 0, out=y, accumulate=True, alpha=0.5)
+        ref = 0.5 * ref + c0.float()
+    assert rel_l2(y, ref) < 4e-3
+    # every tile written exactly once: no stale / missing tile anywhere
+    err = (y.float().cpu() - ref).abs().view(23, 256, 23, 256).amax(dim=(1, 3))
+    assert float(err.max()) < 0.25, err
+
+
 def test_gemm_rejects_bad_shapes():
     ops = _ops()
     x, w = rnd(8, 12).to(DEV), rnd(16, 12).to(DEV)  # K = 12 not a multiple of 8
