@@ -344,7 +344,8 @@ __device__ __forceinline__ bool epilogue_lds_ok(const GemmParams& P, int64_t m0,
     return !P.out_f32 && P.splitk <= 1 && P.dbg_noload != 3 && (P.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(P.C) & 15) == 0 &&
            m0 + T <= P.M && n0 + T <= P.N && (P.residual == nullptr || (P.ldr & 3) == 0);
 }
-__device__ __forceinline__ void epilogue_values4(const GemmParams& P, int64_t m, int64_t n, float (&v)[4]) {
+// bias / per-image bias / activation for 4 consecutive outputs of a full tile
+__device__ __forceinline__ void epilogue_bias_act4(const GemmParams& P, int64_t m, int64_t n, float (&v)[4]) {
     if (P.bias != nullptr) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)P.bias[n + r];
@@ -364,25 +365,31 @@ __device__ __forceinline__ void epilogue_values4(const GemmParams& P, int64_t m,
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
     }
-    if (P.residual != nullptr) {
-        const bf16x4 rv = ld_bf16x4(P.residual + m * P.ldr + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-    }
-    if (P.accumulate) {
-        const bf16x4 c = ld_bf16x4(reinterpret_cast<const bf16*>(P.C) + m * P.ldc + n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)c[r];
-    }
 }
-// wl: this wave's private 8-KiB LDS region (64 rows x 128 bytes); (mw, nw): global origin of the wave's (16 MI) x 64 tile
+// wl: this wave's private 8-KiB LDS region (64 rows x 128 bytes); (mw, nw): global origin of the wave's (16 MI) x 64 tile.
+// A tile that is ADDED to the product (residual, or C itself with `accumulate`) is first brought into the same region with
+// row-contiguous 16-byte loads; each lane then folds its own 8-byte chunk in fp32 and overwrites it in place.
 template <int MI>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& P, f32x4 (&acc)[MI][4], char* wl, int64_t mw, int64_t nw,
                                                   int lane) {
-    const bool plain = P.bias == nullptr && P.rg_bias == nullptr && P.epi == 0 && P.residual == nullptr && !P.accumulate;
     bf16* C = reinterpret_cast<bf16*>(P.C);
+    const bool bias_act = P.bias != nullptr || P.rg_bias != nullptr || P.epi != 0;
+    // the addend staged through LDS: the residual if there is one, else C for `accumulate`
+    const bf16* pre = P.residual != nullptr ? P.residual : (P.accumulate ? C : nullptr);
+    const int64_t ldp = P.residual != nullptr ? P.ldr : P.ldc;
+    const bool pre_lds = pre != nullptr && (ldp & 7) == 0 && (reinterpret_cast<uintptr_t>(pre) & 15) == 0;
+    const bool res_direct = P.residual != nullptr && !pre_lds;            // unaligned residual: 8-byte loads in accumulator layout
+    const bool acc_direct = P.accumulate && (P.residual != nullptr || !pre_lds);
 #pragma unroll
     for (int half = 0; half < MI / 4; ++half) {
+        if (pre_lds) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 8 + (lane >> 3), p = lane & 7;
+                const bf16x8 v = ld_bf16x8(pre + (mw + half * 64 + row) * ldp + nw + p * 8);
+                *reinterpret_cast<bf16x8*>(wl + row * 128 + ((p ^ ((row >> 1) & 7)) << 4)) = v;
+            }
+        }
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii) {
             const int i = half * 4 + ii;
@@ -393,12 +400,28 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& P, f32x4 (&a
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * P.alpha;
-                if (!plain) epilogue_values4(P, mw + i * 16 + (lane & 15), nw + j * 16 + (lane >> 4) * 4, v);
+                const int64_t m = mw + i * 16 + (lane & 15), n = nw + j * 16 + (lane >> 4) * 4;
+                if (bias_act) epilogue_bias_act4(P, m, n, v);
+                bf16x4* slot = reinterpret_cast<bf16x4*>(wl + r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3));
+                if (pre_lds) {
+                    const bf16x4 t = *slot;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
+                }
+                if (res_direct) {
+                    const bf16x4 t = ld_bf16x4(P.residual + m * P.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
+                }
+                if (acc_direct) {
+                    const bf16x4 t = ld_bf16x4(C + m * P.ldc + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
+                }
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-                const int q = (j * 4 + (lane >> 4)) ^ sw;
-                *reinterpret_cast<bf16x4*>(wl + r * 128 + q * 8) = o;
+                *slot = o;
             }
         }
         // wave-private region: only this wave's own LDS traffic has to be ordered (the compiler inserts the lgkmcnt waits)
