@@ -89,6 +89,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
             lse2[qt] = ok ? lsep[qrow] * kLog2e : 0.f;
             dlt[qt] = ok ? dlp[qrow] : 0.f;
         }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) {
+                pin_loaded(qf[qt][ds]);
+                pin_loaded(dof[qt][ds]);
+            }
+            pin_loaded(lse2[qt]);
+            pin_loaded(dlt[qt]);
+        }
     }
 
     int kv_end = sk_len;
@@ -239,6 +249,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
                 vfB[kt][ds] = ok ? ld_bf16x8(vbase + (int64_t)krow * P.k_ss + ds * 32 + g * 8) : zero_bf16x8();
             }
         }
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) {
+                pin_loaded(kfB[kt][ds]);
+                pin_loaded(vfB[kt][ds]);
+            }
     }
     f32x4 dkacc[DT][KT], dvacc[DT][KT];
 #pragma unroll
@@ -296,54 +313,87 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
         if (wave_active) {
             const bool need_mask = (qb0 + BQ > sq_len) || (wk0 + KT * 16 > sk_len) || (CAUSAL && (wk0 + KT * 16 - 1 > qb0 + coff));
             bf16x8 pb[KT][2], dsb[KT][2];
+            // Fragment reads are issued one batch (4 fragments = the operands of the next 4*KT MFMAs) AHEAD of their use and
+            // double-buffered in registers: the compiler's counted lgkmcnt then lets a batch's MFMAs start while the next
+            // batch is still in flight.  Read-then-use in source order made every MFMA pair wait out a full LDS round trip
+            // (78 s_waitcnt per 64 MFMAs, MFMA pipe 18 % busy in rocprofv3 PMC).
+            bf16x8 fr[2][4];
+            auto load_p1 = [&](int buf, int qt, int h) {  // Q and dO row-fragments of q tile qt, d steps 2h and 2h+1
+                fr[buf][0] = Img::frag_row(qt_, qt * 16, 2 * h, lane);
+                fr[buf][1] = Img::frag_row(dot_, qt * 16, 2 * h, lane);
+                fr[buf][2] = Img::frag_row(qt_, qt * 16, 2 * h + 1, lane);
+                fr[buf][3] = Img::frag_row(dot_, qt * 16, 2 * h + 1, lane);
+            };
+            auto load_p2 = [&](int buf, int ks, int dp2) {  // dO and Q column-fragments of d tiles 2*dp2, 2*dp2+1, q rows of ks
+                fr[buf][0] = Img::frag_col_rowimg(dot_, (2 * dp2) * 16, (2 * ks) * 16, (2 * ks + 1) * 16, lane);
+                fr[buf][1] = Img::frag_col_rowimg(qt_, (2 * dp2) * 16, (2 * ks) * 16, (2 * ks + 1) * 16, lane);
+                fr[buf][2] = Img::frag_col_rowimg(dot_, (2 * dp2 + 1) * 16, (2 * ks) * 16, (2 * ks + 1) * 16, lane);
+                fr[buf][3] = Img::frag_col_rowimg(qt_, (2 * dp2 + 1) * 16, (2 * ks) * 16, (2 * ks + 1) * 16, lane);
+            };
+            static_assert(DS == 2 || DS == 4, "two d steps per batch");
+            constexpr int NH = DS / 2;          // batches per q tile in phase 1
+            constexpr int NP1 = 4 * NH;         // phase-1 steps
+            constexpr int NP2 = 2 * (DT / 2);   // phase-2 steps
+            f32x4 s[KT], dp[KT];
+            load_p1(0, 0, 0);
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                f32x4 s[KT], dp[KT];
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int ds = 0; ds < DS; ++ds) {
-                    const bf16x8 qa = Img::frag_row(qt_, qt * 16, ds, lane);
-                    const bf16x8 da = Img::frag_row(dot_, qt * 16, ds, lane);
+            for (int st = 0; st < NP1; ++st) {
+                const int qt = st / NH, h = st % NH;
+                if (st + 1 < NP1)
+                    load_p1((st + 1) & 1, (st + 1) / NH, (st + 1) % NH);
+                else
+                    load_p2((st + 1) & 1, 0, 0);
+                if (h == 0) {
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
-                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kfB[kt][ds], s[kt], 0, 0, 0);
-                        dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vfB[kt][ds], dp[kt], 0, 0, 0);
+                        s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        dp[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 }
-                // acc: lane col = key t, rows q = qt*16 + g*4 + r
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + g * 4);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(dlt_s + qt * 16 + g * 4);
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) {
-                    const int kidx = wk0 + kt * 16 + t;
+                for (int e = 0; e < 2; ++e) {
+                    const int ds = 2 * h + e;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float p = fast_exp2(fmaf(s[kt][r], sl2, -l4[r]));
-                        if (need_mask) {
-                            const int qidx = qb0 + qt * 16 + g * 4 + r;
-                            if (qidx >= sq_len || kidx >= sk_len || (CAUSAL && kidx > qidx + coff)) p = 0.f;
+                    for (int kt = 0; kt < KT; ++kt) {
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[st & 1][2 * e], kfB[kt][ds], s[kt], 0, 0, 0);
+                        dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[st & 1][2 * e + 1], vfB[kt][ds], dp[kt], 0, 0, 0);
+                    }
+                }
+                if (h == NH - 1) {
+                    // acc: lane col = key t, rows q = qt*16 + g*4 + r
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 16 + g * 4);
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dlt_s + qt * 16 + g * 4);
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) {
+                        const int kidx = wk0 + kt * 16 + t;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float p = fast_exp2(fmaf(s[kt][r], sl2, -l4[r]));
+                            if (need_mask) {
+                                const int qidx = qb0 + qt * 16 + g * 4 + r;
+                                if (qidx >= sq_len || kidx >= sk_len || (CAUSAL && kidx > qidx + coff)) p = 0.f;
+                            }
+                            pb[kt][qt >> 1][(qt & 1) * 4 + r] = (bf16)p;
+                            dsb[kt][qt >> 1][(qt & 1) * 4 + r] = (bf16)(p * (dp[kt][r] - d4[r]));
                         }
-                        pb[kt][qt >> 1][(qt & 1) * 4 + r] = (bf16)p;
-                        dsb[kt][qt >> 1][(qt & 1) * 4 + r] = (bf16)(p * (dp[kt][r] - d4[r]));
                     }
                 }
             }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int st = 0; st < NP2; ++st) {
+                const int ks = st / (DT / 2), dp2 = st % (DT / 2);
+                const int buf = (NP1 + st) & 1;
+                if (st + 1 < NP2) load_p2(buf ^ 1, (st + 1) / (DT / 2), (st + 1) % (DT / 2));
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 doc = Img::frag_col_rowimg(dot_, dt * 16, (2 * ks) * 16, (2 * ks + 1) * 16, lane);
-                    const bf16x8 qc = Img::frag_col_rowimg(qt_, dt * 16, (2 * ks) * 16, (2 * ks + 1) * 16, lane);
+                for (int e = 0; e < 2; ++e) {
+                    const int dt = 2 * dp2 + e;
 #pragma unroll
                     for (int kt = 0; kt < KT; ++kt) {
-                        dvacc[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doc, pb[kt][ks], dvacc[dt][kt], 0, 0, 0);
-                        dkacc[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qc, dsb[kt][ks], dkacc[dt][kt], 0, 0, 0);
+                        dvacc[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[buf][2 * e], pb[kt][ks], dvacc[dt][kt], 0, 0, 0);
+                        dkacc[dt][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[buf][2 * e + 1], dsb[kt][ks], dkacc[dt][kt], 0, 0, 0);
                     }
                 }
+            }
         }
         if (it + 1 < niter) lstore((it + 1) & 1);
         __syncthreads();

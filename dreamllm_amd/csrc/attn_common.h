@@ -117,6 +117,15 @@ struct AttnParams {
     int causal;
 };
 
+// Pins a value loaded from global memory BEFORE a loop as "arrived": the empty asm consumes the register, so hipcc places the
+// s_waitcnt vmcnt for it here, once.  Without this the loop header merges "still pending" (the path around the guarded
+// prologue) into the loop, and the first MFMA that reads the register is preceded by s_waitcnt vmcnt(0..1) IN EVERY ITERATION,
+// i.e. right after the next tile's global loads were issued: the wave then sits out a full HBM round trip per iteration.
+template <typename T>
+__device__ __forceinline__ void pin_loaded(const T& v) {
+    asm volatile("" ::"v"(v));
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // raw v_exp_f32 (x <= 0 here)
 
 constexpr float kLog2e = 1.4426950408889634f;

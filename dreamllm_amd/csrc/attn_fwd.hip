@@ -60,6 +60,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
             for (int ds = 0; ds < DS; ++ds)
                 qf[qt][ds] = ld_bf16x8(qbase + (int64_t)min(qrow, sq_len - 1) * P.q_ss + ds * 32 + g * 8);
         }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) pin_loaded(qf[qt][ds]);
     }
 
     int kv_end = sk_len;
