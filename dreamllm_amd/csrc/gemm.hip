@@ -35,6 +35,7 @@ constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
 
 static int g_force_tile = 0;  // test/benchmark override: 0 auto, 128, 256
 static int g_dbg_noload = 0;
+static int g_group_m = 0;   // 0: per-layout default (4 for k-contiguous A, 8 for the weight-gradient layout); else forced
 static int g_glds_pipe = 1;   // software-pipelined direct-to-LDS kernel (default); 0 = plain direct-to-LDS kernel (tile mode 257/258)
 static int g_use_glds = 1;    // direct-to-LDS 256-tile kernel when eligible
 
@@ -62,6 +63,7 @@ struct GemmParams {
     int out_f32;     // C dtype
     int accumulate;  // C += result
     float alpha;     // scale applied to the accumulator before bias
+    int group_m;     // tiles per column group of the grouped tile order (pipe kernel; default 8)
     int dbg_noload;  // benchmark-only: skip the K-loop prefetches (wrong results) to expose the compute+barrier ceiling
     int splitk;      // > 1: blockIdx.y owns a K range and writes raw fp32 partials to ws[split][M][N]
     float* ws;
@@ -836,7 +838,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    constexpr int GROUP_M = 8;
+    const int GROUP_M = P.group_m;
     const int in_group = GROUP_M * num_pid_n;
     const int group_id = wgid / in_group;
     const int first_m = group_id * GROUP_M;
@@ -1050,6 +1052,9 @@ int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bia
     P.M = M; P.N = N; P.K = K; P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldr = ldr;
     P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = accumulate; P.alpha = alpha;
     P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.dbg_noload = g_dbg_noload;
+    // grouped tile order: M rows per column group.  Measured (tools/gemm_groupm_sweep.py): 2-4 is 2-5 % faster than 8 for the
+    // forward / input-gradient layouts (A = activations, M = 32768), 8 is best for the weight gradient; 16+ loses 10 %.
+    P.group_m = g_group_m > 0 ? g_group_m : (layout_a == A_M ? 8 : 4);
     hipStream_t s = (hipStream_t)stream;
     if (layout_a == A_K && layout_b == B_K) return launch_gemm<A_K, B_K>(P, s);
     if (layout_a == A_K && layout_b == B_N) return launch_gemm<A_K, B_N>(P, s);
@@ -1074,6 +1079,10 @@ int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K) {
 
 // tile-size override for tests / microbenchmarks (0 = automatic)
 int dllm_gemm_set_tile(int tile) {
+    if (tile >= 1000 && tile < 1100) {  // benchmark knob: 1000 + GROUP_M of the grouped tile order
+        g_group_m = tile - 1000;  // 1000: back to the per-layout default
+        return DLLM_OK;
+    }
     // 0 auto, 128, 256 (register-staged 256 tile), 257 = 256 tile with the direct-to-LDS kernel where eligible
     // 258: like 257 but WITHOUT the K-loop prefetches (wrong results; exposes the compute+barrier ceiling in microbenchmarks)
     // 259: 257 with the software-pipelined kernel; 260: 259 without the K-loop prefetches (benchmark only)

@@ -1058,3 +1058,33 @@ def attn_decode(q, kcache, vcache, kv_len, scale=None, nsplit=8, out=None):
           kcache.stride(0), kcache.stride(1), kcache.stride(2), out.stride(0), out.stride(1),
           float(scale if scale is not None else D ** -0.5), nsplit, _stream())
     return out
+
+
+# --------------------------------------------------------------------------------------------- torch.compile coexistence
+_DYNAMO_OPAQUE = False
+
+
+def make_dynamo_opaque():
+    """Call once before `torch.compile(model)` (the reference's inference scripts compile the model:
+    projects/dreamllm/inference.py:70, omni/eval/vqa/vqa_inference.py:297; SURVEY.md §8-b1 threading note).
+
+    Every kernel launch of this package goes through ctypes, which Dynamo cannot trace.  This marks each operator entry point
+    of the module (and the autograd Functions behind them) as opaque to Dynamo: it breaks the graph around the call and runs
+    it eagerly on the HIP kernels instead of failing or falling back.  Not applied by default because the wrapper costs a
+    few microseconds per call in plain eager mode."""
+    global _DYNAMO_OPAQUE
+    if _DYNAMO_OPAQUE:
+        return
+    import types
+    g = globals()
+    for name, fn in list(g.items()):
+        if isinstance(fn, types.FunctionType) and fn.__module__ == __name__ and not name.startswith("_") \
+                and name != "make_dynamo_opaque":
+            g[name] = torch.compiler.disable(fn, recursive=True)
+    # autograd Functions that modules call through `.apply` directly
+    fns = [c for c in g.values() if isinstance(c, type) and issubclass(c, torch.autograd.Function) and c.__module__ == __name__]
+    from . import modeling_dreamllm
+    fns.append(modeling_dreamllm._DecoderLayerFn)
+    for c in fns:
+        c.apply = staticmethod(torch.compiler.disable(c.apply, recursive=True))
+    _DYNAMO_OPAQUE = True

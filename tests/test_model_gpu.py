@@ -267,3 +267,30 @@ def test_sdxl_model_stage1_step_matches_manual_composition():
     for n, p in m.named_parameters():
         if p.grad is not None:
             assert rel_l2(p.grad, got[n]) <= 2e-2, n
+
+
+def test_torch_compile_coexistence():
+    """The reference's inference scripts wrap the model in torch.compile (projects/dreamllm/inference.py:70).  After
+    `ops.make_dynamo_opaque()` Dynamo must run the ctypes-launched kernels eagerly around its graph breaks and reproduce the
+    eager logits exactly (backend "eager": no code generation needed on the test box).  Runs in a subprocess because the
+    opaque wrappers are process-global."""
+    import subprocess
+    import sys
+    code = """
+import torch
+from dreamllm_amd import ops
+from dreamllm_amd.factory import TINY, build_dreamllm
+lm = build_dreamllm(TINY, device="cuda", dtype=torch.bfloat16, with_clip=False, with_sd=False).eval()
+ids = torch.randint(3, 30000, (2, 40), device="cuda")
+with torch.no_grad():
+    ref = lm(input_ids=ids, return_dict=True).logits
+ops.make_dynamo_opaque()
+clm = torch.compile(lm, backend="eager")
+with torch.no_grad():
+    out = clm(input_ids=ids, return_dict=True).logits
+assert torch.equal(out, ref), (out - ref).abs().max()
+print("COMPILE_OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       cwd=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    assert "COMPILE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
