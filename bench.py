@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-denoise", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--sharded-grad", action="store_true",
+                    help="N>1: reduce-scatter + sharded AdamW + all-gather (distributed.ShardedGradAdamW) instead of DDP all-reduce")
     return ap.parse_args()
 
 
@@ -151,9 +153,13 @@ def main():
     train = {}
     if not a.no_train:
         model.train()
-        ddp = D.wrap_ddp(model)
         params = [p for p in model.parameters() if p.requires_grad]
-        opt = HipAdamW(params, lr=2e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
+        if a.sharded_grad and world > 1:
+            ddp = model
+            opt = D.ShardedGradAdamW(params, lr=2e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
+        else:
+            ddp = D.wrap_ddp(model)
+            opt = HipAdamW(params, lr=2e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
         if tiny:
             batch = make_interleaved_batch(a.batch, 512, 1, n_dream=8, n_patch=16, seed=1234 + rank, device=dev, image_size=56,
                                            dm_size=128)
@@ -224,7 +230,7 @@ def main():
                                     "random-init weights"),
                        "model": "dreamllm-7b" if not tiny else "tiny", "global_batch": world * a.batch, "per_gpu_batch": a.batch,
                        "seq_len": a.seq_len if not tiny else 512, "images_per_sample": a.images_per_sample,
-                       "parallelism": f"dp{world}", "optimizer": "AdamW bf16 states + global-norm clip 1.0",
+                       "parallelism": f"dp{world}" + ("-shardedgrad" if (a.sharded_grad and world > 1) else ""), "optimizer": "AdamW bf16 states + global-norm clip 1.0",
                        "activation_recompute": "RMSNorm/SwiGLU only (no layer checkpointing)"},
             "loss": train.get("loss"),
             "roofline": train.get("roofline"),

@@ -99,3 +99,127 @@ def reduce_dict(d: dict, average: bool = True) -> dict:
     if average:
         t /= dist.get_world_size()
     return {k: v for k, v in zip(keys, t)}
+
+
+class ShardedGradAdamW:
+    """Sharded-gradient data parallelism: the `shard_grad_op` mode of the reference's stage-II / SFT recipes
+    (omni/train/trainer.py:199-230, projects/dreamllm/configs/stage2/base.py:91-93, omni/utils/fsdp_utils.py:23-61) without FSDP.
+
+    Parameters stay whole on every rank (forward and backward are the plain replica step: no parameter all-gather inside the
+    model, no DDP wrapper); what is sharded is the gradient reduction, the AdamW moments and the update:
+
+        backward  ->  per bucket: reduce_scatter(mean) of the flat gradient   (each rank keeps 1/N of it)
+                  ->  global grad norm = sqrt(all_reduce(sum of the local shards' squares))  -> clip coefficient on device
+                  ->  fused AdamW on the local 1/N slice of the flat parameter buffer (moments exist only for that slice)
+                  ->  all_gather of the updated slices back into the flat parameter buffer
+
+    i.e. ZeRO-2: per-rank optimizer memory drops from 2 x params to 2 x params / N and gradient traffic is one reduce-scatter
+    + one all-gather of the parameter bytes (the same bytes on the wire as DDP's all-reduce), in buckets of `bucket_mb`.
+    The trainable parameters are re-pointed at views of contiguous flat buffers (one per bucket, padded to a multiple of the
+    world size); gradients are accumulated straight into flat gradient buffers (`p.grad` views), so no gather/scatter copies
+    exist.  On the xGMI mesh both collectives are RCCL reduce-scatter / all-gather over the default process group.
+
+    `update_fn(p, g, m, v, lr, b1, b2, eps, wd, step, clip_coef)` defaults to the HIP AdamW kernel (`ops.adamw_`); the CPU
+    tests inject a torch restatement (the product path has no CPU fallback)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None, bucket_mb=512,
+                 state_dtype=None, update_fn=None, sumsq_fn=None, process_group=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.max_grad_norm = max_grad_norm
+        self._step = 0
+        self.last_grad_norm = None
+        if update_fn is None:
+            from . import ops
+
+            def update_fn(p, g, m, v, lr, b1, b2, eps, wd, step, coef):
+                ops.adamw_(p, g, m, v, lr, b1, b2, eps, wd, step, 1.0, coef)
+
+            def sumsq_fn(g):
+                parts = torch.zeros(ops.SUMSQ_PARTS, dtype=torch.float32, device=g.device)
+                ops.sumsq_partials_(g, parts)
+                return ops.reduce_sum_f32(parts)
+        self.update_fn, self.sumsq_fn = update_fn, sumsq_fn
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("no trainable parameters")
+        # buckets in REVERSE registration order: the last layers' gradients are complete first
+        cap = bucket_mb * 1024 * 1024
+        self.buckets, cur, cur_bytes = [], [], 0
+        for p in reversed(params):
+            nb = p.numel() * p.element_size()
+            if cur and (cur_bytes + nb > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nb
+        if cur:
+            self.buckets.append(cur)
+        self.flat_p, self.flat_g, self.shard_m, self.shard_v, self.layout = [], [], [], [], []
+        for bucket in self.buckets:
+            n = sum(p.numel() for p in bucket)
+            padded = (n + self.world - 1) // self.world * self.world
+            fp = torch.zeros(padded, dtype=bucket[0].dtype, device=bucket[0].device)
+            fg = torch.zeros(padded, dtype=bucket[0].dtype, device=bucket[0].device)
+            off = 0
+            for p in bucket:
+                k = p.numel()
+                fp[off:off + k].copy_(p.data.reshape(-1))
+                p.data = fp[off:off + k].view(p.shape)   # the parameter now lives in the flat buffer
+                p.grad = fg[off:off + k].view(p.shape)   # autograd accumulates into the flat gradient buffer
+                off += k
+            shard = padded // self.world
+            sd = state_dtype or bucket[0].dtype
+            self.flat_p.append(fp)
+            self.flat_g.append(fg)
+            self.shard_m.append(torch.zeros(shard, dtype=sd, device=fp.device))
+            self.shard_v.append(torch.zeros(shard, dtype=sd, device=fp.device))
+            self.layout.append((n, padded, shard))
+
+    # ---- optimizer-like surface ------------------------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients live in the flat buffers: they are zeroed in place (set_to_none would detach the views)."""
+        for fg in self.flat_g:
+            fg.zero_()
+
+    def state_bytes_per_rank(self) -> int:
+        return sum(m.numel() * m.element_size() + v.numel() * v.element_size() for m, v in zip(self.shard_m, self.shard_v))
+
+    @torch.no_grad()
+    def step(self):
+        self._step += 1
+        W, r = self.world, self.rank
+        gshards = []
+        for fg, (n, padded, shard) in zip(self.flat_g, self.layout):
+            if W > 1:
+                out = torch.empty(shard, dtype=fg.dtype, device=fg.device)
+                try:
+                    dist.reduce_scatter_tensor(out, fg, op=dist.ReduceOp.SUM, group=self.pg)
+                except RuntimeError:  # transport without a reduce-scatter for this device type (gloo + CUDA tensors in tests)
+                    dist.all_reduce(fg, op=dist.ReduceOp.SUM, group=self.pg)
+                    out.copy_(fg[r * shard:(r + 1) * shard])
+                out.div_(W)  # mean, as DDP (ReduceOp.AVG is not available on every backend)
+            else:
+                out = fg[:shard]
+            gshards.append(out)
+        coef = None
+        if self.max_grad_norm is not None:
+            sq = torch.stack([self.sumsq_fn(g).reshape(()) for g in gshards]).sum()
+            if W > 1:
+                dist.all_reduce(sq, op=dist.ReduceOp.SUM, group=self.pg)
+            norm = sq.sqrt()
+            self.last_grad_norm = norm
+            coef = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0).reshape(1).to(torch.float32)
+        b1, b2 = self.betas
+        for fp, g, m, v, (n, padded, shard) in zip(self.flat_p, gshards, self.shard_m, self.shard_v, self.layout):
+            pshard = fp[r * shard:(r + 1) * shard]
+            self.update_fn(pshard, g, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self._step, coef)
+            if W > 1:
+                try:
+                    dist.all_gather_into_tensor(fp, pshard.clone(), group=self.pg)
+                except RuntimeError:
+                    parts = [torch.empty_like(pshard) for _ in range(W)]
+                    dist.all_gather(parts, pshard.clone(), group=self.pg)
+                    fp.copy_(torch.cat(parts))

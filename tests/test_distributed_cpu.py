@@ -71,3 +71,78 @@ def test_shard_partition_is_disjoint_and_complete():
     for n, w in ((128, 8), (10, 4), (3, 8)):
         seen = [i for r in range(w) for i in shard_for_rank(n, r, w)]
         assert sorted(seen) == list(range(n))
+
+
+# ------------------------------------------------------------------------------------------ sharded-gradient mode (ZeRO-2)
+def _torch_adamw(p, g, m, v, lr, b1, b2, eps, wd, step, coef):
+    """torch restatement of the fused AdamW kernel (decoupled weight decay, bias correction, optional clip coefficient)."""
+    g = g.float() * (coef.float() if coef is not None else 1.0)
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    mh = m / (1 - b1 ** step)
+    vh = v / (1 - b2 ** step)
+    p.mul_(1 - lr * wd).sub_(lr * mh / (vh.sqrt() + eps))
+
+
+def _sumsq(g):
+    return (g.float() ** 2).sum()
+
+
+def _sharded_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dreamllm_amd import distributed as D
+    D.init_distributed("gloo")
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 13), torch.nn.Tanh(), torch.nn.Linear(13, 3))  # odd sizes: padding path
+    opt = D.ShardedGradAdamW(model.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1, max_grad_norm=0.5,
+                             bucket_mb=1, update_fn=_torch_adamw, sumsq_fn=_sumsq)
+    data = torch.arange(80, dtype=torch.float32).view(10, 8) / 80.0
+    x = data[list(D.shard_for_rank(10))]
+    norms = []
+    for _ in range(3):
+        opt.zero_grad()
+        model(x).pow(2).mean().backward()
+        opt.step()
+        norms.append(float(opt.last_grad_norm))
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    q.put((rank, flat.tolist(), norms, opt.state_bytes_per_rank()))
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_grad_adamw_matches_single_process_adamw():
+    """2 ranks, gloo: reduce-scatter(mean) -> global-norm clip -> AdamW on the local slice -> all-gather reproduces a
+    single-process AdamW step on the mean gradient; both ranks end with identical parameters; moments are half-size."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (_, f0, n0, sb0), (_, f1, n1, sb1) = res
+    assert f0 == f1 and n0 == n1  # replicas bit-identical after 3 steps
+    # reference: one process, mean of the two shard losses, torch AdamW semantics with clip_grad_norm_
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 13), torch.nn.Tanh(), torch.nn.Linear(13, 3))
+    params = list(model.parameters())
+    ms = [torch.zeros_like(p) for p in params]
+    vs = [torch.zeros_like(p) for p in params]
+    data = torch.arange(80, dtype=torch.float32).view(10, 8) / 80.0
+    norms = []
+    for step in range(1, 4):
+        model.zero_grad()
+        (0.5 * (model(data[:5]).pow(2).mean() + model(data[5:]).pow(2).mean())).backward()
+        norm = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in params))
+        norms.append(float(norm))
+        coef = torch.clamp(0.5 / (norm + 1e-6), max=1.0)
+        with torch.no_grad():
+            for p, m, v in zip(params, ms, vs):
+                _torch_adamw(p, p.grad, m, v, 1e-2, 0.9, 0.95, 1e-8, 0.1, step, coef)
+    ref = torch.cat([p.detach().flatten() for p in params])
+    assert torch.allclose(torch.tensor(f0), ref, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(torch.tensor(n0), torch.tensor(norms), rtol=1e-5)
+    n_params = sum(p.numel() for p in params)
+    assert sb0 == sb1 and sb0 <= 2 * 4 * (n_params // 2 + 4)  # two fp32 moments over half the parameters (+ padding)
