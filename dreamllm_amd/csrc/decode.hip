@@ -73,6 +73,160 @@ int launch_gemv(const bf16* x, const bf16* W, void* y, const bf16* r, int64_t N,
     return dllm_check_launch();
 }
 
+// ---- fused decode GEMVs ---------------------------------------------------------------------------------------------------
+// Token step launches drop from 17 to 7 per layer with these (each tiny kernel costs 3-8 us inside the graph):
+//   * gemv_fused_kernel<MB, SWIGLU = false>: optional RMSNorm of x folded in (each wave recomputes rstd from the row it reads
+//     anyway, with the same lane/vector order as rmsnorm_fwd_kernel so the two roundings t = bf16(x rstd), h = bf16(w t) are
+//     reproduced), up to three weight matrices in one launch (q, k, v: rows are concatenated), bf16 or fp32 output.
+//   * SWIGLU = true: row n of W0 (gate) and of W1 (up) in the same wave, output act[n] = bf16(silu(bf16 g) * bf16 u) -- the
+//     values DreamLLMMLP.forward (modeling_dreamllm.py:237) rounds to.
+struct GemvFusedParams {
+    const bf16* x;        // [M][ldx]
+    const bf16* norm_w;   // [K] or null
+    float eps;
+    const bf16* W[3];     // [N_i][ldw]
+    void* y[3];           // [M][ldy_i]
+    int64_t N[3];
+    int64_t ldy[3];
+    const bf16* residual;  // added to y[0] (single-matrix use) or null
+    int64_t ldr;
+    int K;
+    int64_t ldx, ldw;
+    int out_f32;
+};
+
+template <int MB, bool SWIGLU>
+__global__ __launch_bounds__(256) void gemv_fused_kernel(GemvFusedParams P) {
+    constexpr int UNROLL = 4;
+    const int lane = threadIdx.x & 63;
+    int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    int mat = 0;
+    if constexpr (!SWIGLU) {
+        if (n >= P.N[0]) {
+            n -= P.N[0];
+            mat = 1;
+            if (n >= P.N[1]) {
+                n -= P.N[1];
+                mat = 2;
+            }
+        }
+    }
+    if (n >= P.N[mat]) return;
+    const int K = P.K;
+    float rstd[MB];
+    if (P.norm_w != nullptr) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            float ss = 0.f;
+            for (int k = lane * 8; k < K; k += 512) {
+                const bf16x8 xv = ld_bf16x8(P.x + m * P.ldx + k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += (float)xv[e] * (float)xv[e];
+            }
+            ss = wave_sum(ss);
+            rstd[m] = rsqrtf(ss / (float)K + P.eps);
+        }
+    }
+    const bf16* w0 = P.W[mat] + n * P.ldw;
+    const bf16* w1 = SWIGLU ? P.W[1] + n * P.ldw : nullptr;
+    float acc[MB], acc1[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = acc1[m] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 512 * UNROLL) {
+        bf16x8 wa[UNROLL], wb[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int k = k0 + u * 512 + lane * 8;
+            wa[u] = k < K ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w0 + k)) : zero_bf16x8();
+            if constexpr (SWIGLU) wb[u] = k < K ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + k)) : zero_bf16x8();
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int k = k0 + u * 512 + lane * 8;
+            if (k < K) {
+                bf16x8 nw = zero_bf16x8();
+                if (P.norm_w != nullptr) nw = ld_bf16x8(P.norm_w + k);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const bf16x8 xv = ld_bf16x8(P.x + m * P.ldx + k);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float xe = (float)xv[e];
+                        if (P.norm_w != nullptr) {
+                            const bf16 t = (bf16)(xe * rstd[m]);          // .to(input_dtype)
+                            xe = (float)(bf16)((float)nw[e] * (float)t);  // weight * (.)
+                        }
+                        acc[m] = fmaf((float)wa[u][e], xe, acc[m]);
+                        if constexpr (SWIGLU) acc1[m] = fmaf((float)wb[u][e], xe, acc1[m]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+        float v = wave_sum(acc[m]);
+        float v1 = 0.f;
+        if constexpr (SWIGLU) v1 = wave_sum(acc1[m]);
+        if (lane == 0) {
+            if constexpr (SWIGLU) {
+                const float g = (float)(bf16)v, u = (float)(bf16)v1;
+                reinterpret_cast<bf16*>(P.y[0])[m * P.ldy[0] + n] = (bf16)(silu_f(g) * u);
+            } else {
+                if (P.residual != nullptr && mat == 0) v += (float)P.residual[m * P.ldr + n];
+                if (P.out_f32)
+                    reinterpret_cast<float*>(P.y[mat])[m * P.ldy[mat] + n] = v;
+                else
+                    reinterpret_cast<bf16*>(P.y[mat])[m * P.ldy[mat] + n] = (bf16)v;
+            }
+        }
+    }
+}
+
+template <int MB>
+int launch_gemv_fused(const GemvFusedParams& P, int swiglu, hipStream_t s) {
+    const int64_t rows = swiglu ? P.N[0] : P.N[0] + P.N[1] + P.N[2];
+    const unsigned grid = (unsigned)cdiv64(rows, 4);
+    if (swiglu)
+        hipLaunchKernelGGL((gemv_fused_kernel<MB, true>), dim3(grid), dim3(256), 0, s, P);
+    else
+        hipLaunchKernelGGL((gemv_fused_kernel<MB, false>), dim3(grid), dim3(256), 0, s, P);
+    return dllm_check_launch();
+}
+
+// RoPE on the new token's q and k (modeling_dreamllm.py:184-209) + append of k, v to the KV cache, one launch.
+// q [B][H][D] in place; k [B][Hkv][D] rotated into kcache[b][pos[b]]; v copied into vcache[b][pos[b]].  pos on device.
+__global__ __launch_bounds__(64) void rope_append_kernel(bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
+                                                         bf16* __restrict__ kc, bf16* __restrict__ vc, const float* __restrict__ cs,
+                                                         const float* __restrict__ sn, const int64_t* __restrict__ pos, int H,
+                                                         int Hkv, int D, int64_t q_sb, int64_t kv_sb, int64_t c_sb, int64_t c_ss,
+                                                         int64_t c_sh) {
+    const int b = blockIdx.y, hh = blockIdx.x, half = D >> 1;
+    const int64_t p = pos[b];
+    const int i = threadIdx.x;  // pair index
+    if (i >= half) return;
+    const float c = cs[p * half + i], s = sn[p * half + i];
+    if (hh < H) {
+        bf16* x = q + (int64_t)b * q_sb + (int64_t)hh * D;
+        const float x1 = (float)x[i], x2 = (float)x[i + half];
+        x[i] = (bf16)(x1 * c - x2 * s);
+        x[i + half] = (bf16)(x2 * c + x1 * s);
+    } else if (hh < H + Hkv) {
+        const int hk = hh - H;
+        const bf16* x = k + (int64_t)b * kv_sb + (int64_t)hk * D;
+        bf16* dst = kc + (int64_t)b * c_sb + p * c_ss + (int64_t)hk * c_sh;
+        const float x1 = (float)x[i], x2 = (float)x[i + half];
+        dst[i] = (bf16)(x1 * c - x2 * s);
+        dst[i + half] = (bf16)(x2 * c + x1 * s);
+    } else {
+        const int hk = hh - H - Hkv;
+        const bf16* x = v + (int64_t)b * kv_sb + (int64_t)hk * D;
+        bf16* dst = vc + (int64_t)b * c_sb + p * c_ss + (int64_t)hk * c_sh;
+        dst[i] = x[i];
+        dst[i + half] = x[i + half];
+    }
+}
+
 // ---- decode attention -------------------------------------------------------------------------------------------------
 struct Partial {  // running softmax state of one lane: 8 of the D output dims of its key group
     float m, l, o[8];
@@ -214,6 +368,50 @@ int dllm_gemv_bf16(const void* x, const void* W, void* y, const void* residual, 
         case 7: return launch_gemv<7>(xp, wp, y, rp, N, (int)K, ldx, ldw, ldy, ldr, f32, s);
         default: return launch_gemv<8>(xp, wp, y, rp, N, (int)K, ldx, ldw, ldy, ldr, f32, s);
     }
+}
+
+// Fused decode GEMV: y_i[M][N_i] = h W_i^T, h = RMSNorm(x; norm_w, eps) if norm_w else x; i < nmat <= 3 matrices sharing K and ldw
+// (q/k/v projections in one launch), optional residual added to y_0.  swiglu != 0: nmat must be 2 (gate, up) and the single
+// output y_0[M][N_0] = silu(gate) * up.  M <= 8.
+int dllm_gemv_fused(const void* x, const void* norm_w, float eps, const void* W0, const void* W1, const void* W2, void* y0, void* y1,
+                    void* y2, const void* residual, int M, int64_t N0, int64_t N1, int64_t N2, int64_t K, int64_t ldx, int64_t ldw,
+                    int64_t ldy0, int64_t ldy1, int64_t ldy2, int64_t ldr, int swiglu, int out_dtype, void* stream) {
+    if (M < 0 || M > 8 || N0 < 0 || N1 < 0 || N2 < 0 || K <= 0 || K > 0x7fffffff) return DLLM_ERR_SHAPE;
+    if ((K & 7) || (ldx & 7) || (ldw & 7)) return DLLM_ERR_ALIGN;
+    if (swiglu && (W1 == nullptr || N1 != N0 || N2 != 0 || out_dtype != DLLM_BF16 || residual != nullptr)) return DLLM_ERR_SHAPE;
+    if ((N1 > 0 && (W1 == nullptr || (!swiglu && y1 == nullptr))) || (N2 > 0 && (W2 == nullptr || y2 == nullptr))) return DLLM_ERR_SHAPE;
+    if (out_dtype != DLLM_BF16 && out_dtype != DLLM_F32) return DLLM_ERR_DTYPE;
+    if (M == 0 || N0 == 0) return DLLM_OK;
+    GemvFusedParams P{};
+    P.x = (const bf16*)x; P.norm_w = (const bf16*)norm_w; P.eps = eps;
+    P.W[0] = (const bf16*)W0; P.W[1] = (const bf16*)W1; P.W[2] = (const bf16*)W2;
+    P.y[0] = y0; P.y[1] = y1; P.y[2] = y2;
+    P.N[0] = N0; P.N[1] = swiglu ? N0 : N1; P.N[2] = N2;
+    P.ldy[0] = ldy0; P.ldy[1] = ldy1; P.ldy[2] = ldy2;
+    P.residual = (const bf16*)residual; P.ldr = ldr; P.K = (int)K; P.ldx = ldx; P.ldw = ldw; P.out_f32 = out_dtype == DLLM_F32;
+    hipStream_t s = (hipStream_t)stream;
+    switch (M) {
+        case 1: return launch_gemv_fused<1>(P, swiglu, s);
+        case 2: return launch_gemv_fused<2>(P, swiglu, s);
+        case 3: return launch_gemv_fused<3>(P, swiglu, s);
+        case 4: return launch_gemv_fused<4>(P, swiglu, s);
+        case 5: return launch_gemv_fused<5>(P, swiglu, s);
+        case 6: return launch_gemv_fused<6>(P, swiglu, s);
+        case 7: return launch_gemv_fused<7>(P, swiglu, s);
+        default: return launch_gemv_fused<8>(P, swiglu, s);
+    }
+}
+
+// RoPE of the step's q (in place) and k, append of rotated k and v to the caches at position pos[b] (device int64 [B]).
+int dllm_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
+                     const int64_t* pos, int B, int H, int Hkv, int D, int64_t q_sb, int64_t kv_sb, int64_t c_sb, int64_t c_ss,
+                     int64_t c_sh, void* stream) {
+    if (B < 0 || H <= 0 || Hkv <= 0 || (D != 64 && D != 128) || pos == nullptr) return DLLM_ERR_SHAPE;
+    if (B == 0) return DLLM_OK;
+    hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)(H + 2 * Hkv), (unsigned)B), dim3(64), 0, (hipStream_t)stream, (bf16*)q,
+                       (const bf16*)k, (const bf16*)v, (bf16*)kcache, (bf16*)vcache, cos_tab, sin_tab, pos, H, Hkv, D, q_sb, kv_sb,
+                       c_sb, c_ss, c_sh);
+    return dllm_check_launch();
 }
 
 // floats of workspace dllm_attn_decode needs

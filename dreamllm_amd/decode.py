@@ -5,9 +5,9 @@ DreamLLMForCausalMLM.forward (modeling_dreamllm.py:1353) with `use_cache=True`. 
 per token (~15 kernels x 32 layers + host logic); at batch 1 that is launch-bound by an order of magnitude over the weight
 stream.  Here the token step is a fixed sequence of launches on static buffers:
 
-    embed[tok] -> 32 x { RMSNorm -> q/k/v GEMV -> RoPE(pos on device) -> K/V appended to the cache at pos (index_copy on a
-    device index) -> decode attention over the cache (valid length on device) -> o GEMV + residual -> RMSNorm -> gate/up GEMV ->
-    SwiGLU -> down GEMV + residual } -> final RMSNorm -> lm_head GEMV (fp32 logits) -> argmax -> pos/len/step += 1
+    embed[tok] -> 32 x { [RMSNorm + q/k/v GEMV] -> [RoPE(pos on device) + K/V append to the cache at pos] -> decode attention
+    over the cache (valid length on device) -> [o GEMV + residual] -> [RMSNorm + gate/up GEMV + SwiGLU] -> [down GEMV + residual] }
+    -> [final RMSNorm + lm_head GEMV] (fp32 logits) -> argmax -> pos/len/step += 1      ([..] = one launch; 7 per layer)
 
 captured once per (batch, max_len) in a hipGraph (`torch.cuda.CUDAGraph`) and replayed per token; nothing in it depends on the
 host.  Prefill runs through the normal model forward (MFMA GEMMs + flash attention) and its K/V are copied into the cache.
@@ -22,10 +22,10 @@ from . import ops
 
 
 class GreedyDecodeSession:
-    def __init__(self, model, batch_size: int, max_len: int, use_graph: bool = True, nsplit: int = 8):
+    def __init__(self, model, batch_size: int, max_len: int, use_graph: bool = True, nsplit: int = 8, fused: bool = True):
         cfg = model.config
         self.model = model
-        self.B, self.max_len, self.use_graph, self.nsplit = batch_size, max_len, use_graph, nsplit
+        self.B, self.max_len, self.use_graph, self.nsplit, self.fused = batch_size, max_len, use_graph, nsplit, fused
         if batch_size > 8:
             raise ValueError("the decode GEMV handles up to 8 sequences per step")
         dev, dt = model.device, model.dtype
@@ -52,8 +52,22 @@ class GreedyDecodeSession:
         B, H, Hkv, D = self.B, self.H, self.Hkv, self.D
         eps = cfg.rms_norm_eps
         x = m.model.embed_tokens.weight.index_select(0, self.tok)  # [B, d]
+        pos = self.pos.view(-1)
         for li, layer in enumerate(m.model.layers):
             at, mlp = layer.self_attn, layer.mlp
+            if self.fused:
+                # 7 launches per layer: [RMSNorm + q/k/v GEMV] [RoPE + cache append] [attention x2] [o GEMV + residual]
+                # [RMSNorm + gate/up GEMV + SwiGLU] [down GEMV + residual]
+                q, k, v = ops.gemv_fused(x, (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight),
+                                         norm_w=layer.input_layernorm.weight, eps=eps)
+                q = q.view(B, H, D)
+                ops.rope_append_(q, k.view(B, Hkv, D), v.view(B, Hkv, D), self.kc[li], self.vc[li], self.cos, self.sin, pos)
+                o = ops.attn_decode(q, self.kc[li], self.vc[li], self.kv_len, 1.0 / math.sqrt(D), self.nsplit)
+                x2 = ops.gemv(o.view(B, H * D), at.o_proj.weight, residual=x)
+                act = ops.gemv_fused(x2, (mlp.gate_proj.weight, mlp.up_proj.weight), norm_w=layer.post_attention_layernorm.weight,
+                                     eps=eps, swiglu=True)
+                x = ops.gemv(act, mlp.down_proj.weight, residual=x2)
+                continue
             h, _, _ = ops.rmsnorm_fwd(x, layer.input_layernorm.weight, eps)
             q = ops.gemv(h, at.q_proj.weight).view(B, 1, H, D)
             k = ops.gemv(h, at.k_proj.weight).view(B, 1, Hkv, D)
@@ -68,8 +82,11 @@ class GreedyDecodeSession:
             g = ops.gemv(h2, mlp.gate_proj.weight)
             u = ops.gemv(h2, mlp.up_proj.weight)
             x = ops.gemv(ops.glu_fwd(g, u, 0), mlp.down_proj.weight, residual=x2)
-        hf, _, _ = ops.rmsnorm_fwd(x, m.model.norm.weight, eps)
-        logits = ops.gemv(hf, m.lm_head.weight, out_dtype=torch.float32)
+        if self.fused:
+            logits = ops.gemv_fused(x, (m.lm_head.weight,), norm_w=m.model.norm.weight, eps=eps, out_dtype=torch.float32)[0]
+        else:
+            hf, _, _ = ops.rmsnorm_fwd(x, m.model.norm.weight, eps)
+            logits = ops.gemv(hf, m.lm_head.weight, out_dtype=torch.float32)
         nxt = logits.argmax(-1)
         self.out_tokens.index_copy_(0, self.step_idx, nxt[None])
         self.tok.copy_(nxt)

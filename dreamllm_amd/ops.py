@@ -1088,3 +1088,54 @@ def make_dynamo_opaque():
     for c in fns:
         c.apply = staticmethod(torch.compiler.disable(c.apply, recursive=True))
     _DYNAMO_OPAQUE = True
+
+
+def gemv_fused(x, weights, norm_w=None, eps=0.0, residual=None, swiglu=False, out_dtype=torch.bfloat16):
+    """Decode-step Linear(s) in one launch: h = RMSNorm(x; norm_w, eps) if norm_w is given else x; then
+    `swiglu=False`: [h W_i^T for W_i in weights] (1..3 matrices sharing K; residual is added to the first),
+    `swiglu=True`: weights = (gate, up) -> silu(h gate^T) * (h up^T).  x [M<=8, K]."""
+    _need_gpu(x, norm_w, residual, *weights)
+    _bf16(x, norm_w, residual, *weights)
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    M, K = x2.shape
+    ws = [w if w.is_contiguous() else w.contiguous() for w in weights]
+    if any(w.shape[1] != K for w in ws) or not 1 <= len(ws) <= 3:
+        raise ValueError("gemv_fused: 1..3 weight matrices with a common K")
+    Ns = [w.shape[0] for w in ws]
+    if swiglu:
+        if len(ws) != 2 or Ns[0] != Ns[1]:
+            raise ValueError("gemv_fused(swiglu): weights = (gate, up) of equal shape")
+        outs = [torch.empty(M, Ns[0], dtype=torch.bfloat16, device=x.device)]
+    else:
+        outs = [torch.empty(M, n, dtype=out_dtype, device=x.device) for n in Ns]
+    r2 = None
+    if residual is not None:
+        r2 = residual.reshape(-1, Ns[0])
+        if r2.stride(-1) != 1:
+            r2 = r2.contiguous()
+    wp = [_p(w) for w in ws] + [None] * (3 - len(ws))
+    yp = [_p(o) for o in outs] + [None] * (3 - len(outs))
+    nn_ = Ns + [0] * (3 - len(Ns))
+    ldy = [o.stride(0) for o in outs] + [0] * (3 - len(outs))
+    check("dllm_gemv_fused", _p(x2), _p(norm_w), float(eps), wp[0], wp[1], wp[2], yp[0], yp[1], yp[2], _p(r2), M, nn_[0],
+          nn_[1], nn_[2], K, x2.stride(0), K, ldy[0], ldy[1], ldy[2], r2.stride(0) if r2 is not None else 0,
+          int(swiglu), _dt(outs[0]), _stream())
+    return outs[0] if swiglu else outs
+
+
+def rope_append_(q, k, v, kcache, vcache, cos, sin, pos):
+    """q [B,H,D] rotated in place; k [B,Hkv,D] rotated into kcache[b, pos[b]]; v copied into vcache[b, pos[b]] (pos: int64 [B] on
+    device).  caches [B,Smax,Hkv,D] with identical strides."""
+    _need_gpu(q, k, v, kcache, vcache, cos, sin, pos)
+    _bf16(q, k, v, kcache, vcache)
+    B, H, D = q.shape
+    Hkv = k.shape[1]
+    if not (q.is_contiguous() and k.is_contiguous() and v.is_contiguous()) or kcache.stride() != vcache.stride():
+        raise ValueError("rope_append_: contiguous q/k/v and equal cache strides required")
+    if pos.dtype != torch.int64:
+        raise TypeError("rope_append_: pos must be int64")
+    check("dllm_rope_append", _p(q), _p(k), _p(v), _p(kcache), _p(vcache), _p(cos), _p(sin), _p(pos.reshape(-1)), B, H, Hkv, D,
+          q.stride(0), k.stride(0), kcache.stride(0), kcache.stride(1), kcache.stride(2), _stream())
+    return q

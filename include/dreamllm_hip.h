@@ -172,6 +172,14 @@ int dllm_cfg_ddim_step(const void* pred, float* latents, void* next_in, int64_t 
  * dllm_attn_decode_ws_floats(B, H, D, nsplit) elements (split-KV partial softmax states). */
 int dllm_gemv_bf16(const void* x, const void* W, void* y, const void* residual, int M, int64_t N, int64_t K, int64_t ldx,
                    int64_t ldw, int64_t ldy, int64_t ldr, int out_dtype, void* stream);
+/* fused forms that cut the token step from 17 to 7 launches per layer: RMSNorm folded into the GEMV (same roundings as
+ * dllm_rmsnorm_fwd), q/k/v in one launch, gate/up + SwiGLU in one launch; RoPE (q in place, k) + KV-cache append in one. */
+int dllm_gemv_fused(const void* x, const void* norm_w, float eps, const void* W0, const void* W1, const void* W2, void* y0, void* y1,
+                    void* y2, const void* residual, int M, int64_t N0, int64_t N1, int64_t N2, int64_t K, int64_t ldx, int64_t ldw,
+                    int64_t ldy0, int64_t ldy1, int64_t ldy2, int64_t ldr, int swiglu, int out_dtype, void* stream);
+int dllm_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
+                     const int64_t* pos, int B, int H, int Hkv, int D, int64_t q_sb, int64_t kv_sb, int64_t c_sb, int64_t c_ss,
+                     int64_t c_sh, void* stream);
 int64_t dllm_attn_decode_ws_floats(int B, int H, int D, int nsplit);
 int dllm_attn_decode(const void* q, const void* kcache, const void* vcache, const int* kv_len, void* out, float* ws, int B, int H,
                      int Hkv, int D, int64_t q_sb, int64_t q_sh, int64_t c_sb, int64_t c_ss, int64_t c_sh, int64_t o_sb,

@@ -544,3 +544,41 @@ def test_attn_decode(B, H, Hkv, D, Smax, lens, nsplit):
         p = torch.softmax(torch.einsum("hd,nhd->hn", q[b].float(), k) * D ** -0.5, dim=-1)
         ref = torch.einsum("hn,nhd->hd", p, v)
         assert rel_l2(out[b], ref) < 6e-3, (b, n)
+
+
+def test_gemv_fused_norm_multi_swiglu_and_rope_append():
+    """Fused decode launches against the unfused operator chain they replace: bit-identical (same roundings, same
+    accumulation order) for RMSNorm + q/k/v, RMSNorm + gate/up + SwiGLU, RMSNorm + fp32 head; RoPE + cache append."""
+    ops = _ops()
+    M, K, F_ = 3, 4096, 1376
+    x, nw = rnd(M, K, seed=1).to(DEV), (1.0 + 0.1 * torch.randn(K)).to(BF).to(DEV)
+    wq, wk, wv = (rnd(n, K, scale=0.03).to(DEV) for n in (512, 256, 256))
+    h, _, _ = ops.rmsnorm_fwd(x, nw, 1e-5)
+    q, k, v = ops.gemv_fused(x, (wq, wk, wv), norm_w=nw, eps=1e-5)
+    for got, w in ((q, wq), (k, wk), (v, wv)):
+        assert torch.equal(got, ops.gemv(h, w))
+    wg, wu = rnd(F_, K, scale=0.03).to(DEV), rnd(F_, K, scale=0.03).to(DEV)
+    act = ops.gemv_fused(x, (wg, wu), norm_w=nw, eps=1e-5, swiglu=True)
+    assert torch.equal(act, ops.glu_fwd(ops.gemv(h, wg), ops.gemv(h, wu), 0))
+    r = rnd(M, 512).to(DEV)
+    y = ops.gemv_fused(x, (wq,), residual=r)[0]  # no norm, residual
+    assert torch.equal(y, ops.gemv(x, wq, residual=r))
+    lg = ops.gemv_fused(x, (wq,), norm_w=nw, eps=1e-5, out_dtype=torch.float32)[0]
+    assert lg.dtype == torch.float32 and torch.equal(lg, ops.gemv(h, wq, out_dtype=torch.float32))
+    # rope + append
+    B, H, Hkv, D, S = 3, 4, 2, 128, 50
+    qq, kk, vv = rnd(B, H, D, seed=2).to(DEV), rnd(B, Hkv, D).to(DEV), rnd(B, Hkv, D).to(DEV)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(S).float()[:, None] * inv[None]
+    cos, sin = ang.cos().to(DEV), ang.sin().to(DEV)
+    pos = torch.tensor([0, 17, 49], device=DEV)
+    kc = torch.zeros(B, S, Hkv, D, dtype=BF, device=DEV)
+    vc = torch.zeros_like(kc)
+    q_ref, k_ref = qq.clone().view(B, 1, H, D), kk.clone().view(B, 1, Hkv, D)
+    ops.rope_(q_ref, cos, sin, pos[:, None])
+    ops.rope_(k_ref, cos, sin, pos[:, None])
+    ops.rope_append_(qq, kk, vv, kc, vc, cos, sin, pos)
+    assert torch.equal(qq, q_ref.view(B, H, D))
+    for b in range(B):
+        assert torch.equal(kc[b, pos[b]], k_ref[b, 0]) and torch.equal(vc[b, pos[b]], vv[b])
+    assert int((kc != 0).any(dim=-1).any(dim=-1).sum()) == B  # exactly one cache row per batch element written

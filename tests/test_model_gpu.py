@@ -171,7 +171,7 @@ def test_causal_mlm_fast_index_path_matches(golden):
     assert torch.equal(a.logits, b.logits) and torch.equal(a.loss, b.loss)
 
 
-@pytest.mark.parametrize("mode", ["graph", "kernels", "model"])
+@pytest.mark.parametrize("mode", ["graph", "kernels", "unfused", "model"])
 def test_greedy_decode_golden(golden, mode):
     """BASELINE config 1 plumbing: KV-cache prefill + 8 greedy steps reproduce the reference's token ids -- through the
     decode kernels replayed as a hipGraph ("graph"), the same kernels launched eagerly ("kernels"), and the per-token model
@@ -179,7 +179,13 @@ def test_greedy_decode_golden(golden, mode):
     g = golden("causal_mlm.pt")
     gd = golden("greedy_decode.pt")
     lm = _build_lm(g).eval()
-    toks = lm.greedy_generate(gd["prompt"].to(DEV), 8, fast=mode != "model", use_graph=mode == "graph")
+    if mode == "unfused":  # the 17-launch-per-layer token step (every operator on its own)
+        from dreamllm_amd.decode import GreedyDecodeSession
+        sess = GreedyDecodeSession(lm, 1, gd["prompt"].shape[1] + 9, use_graph=False, fused=False)
+        first = sess.prefill(gd["prompt"].to(DEV))
+        toks = torch.cat([gd["prompt"].to(DEV), first[:, None], sess.generate(7)], 1)
+    else:
+        toks = lm.greedy_generate(gd["prompt"].to(DEV), 8, fast=mode != "model", use_graph=mode == "graph")
     # bf16 logits can flip an argmax only on near-ties; require the reference sequence (seeded, no ties in the fixture)
     assert torch.equal(toks.cpu(), gd["tokens"]), (toks.cpu(), gd["tokens"])
 

@@ -160,6 +160,28 @@ def bench_elementwise(out):
          frac_hbm_peak=round(gb / PEAK_GBS, 4))
 
 
+def bench_gemv(out):
+    """Decode-step GEMVs at the 7B layer shapes (weights streamed once: HBM-bound)."""
+    for name, N, K in [("o_proj", 4096, 4096), ("down_proj", 4096, 11008), ("lm_head", 32008, 4096)]:
+        x = torch.randn(1, K, device="cuda").to(BF)
+        w = (torch.randn(N, K, device="cuda") * 0.02).to(BF)
+        ms = timeit(lambda: ops.gemv(x, w), iters=50, warmup=5)
+        gb = N * K * 2 / ms / 1e6
+        emit(out, kernel="gemv", name=name, N=N, K=K, ms=round(ms, 4), gbs=round(gb, 1), frac_hbm_peak=round(gb / PEAK_GBS, 4))
+    K = 4096
+    x = torch.randn(1, K, device="cuda").to(BF)
+    nw = torch.ones(K, device="cuda", dtype=BF)
+    ws = [(torch.randn(4096, K, device="cuda") * 0.02).to(BF) for _ in range(3)]
+    ms = timeit(lambda: ops.gemv_fused(x, ws, norm_w=nw, eps=1e-5), iters=50, warmup=5)
+    gb = 3 * 4096 * K * 2 / ms / 1e6
+    emit(out, kernel="gemv_fused", name="rmsnorm+qkv", N=12288, K=K, ms=round(ms, 4), gbs=round(gb, 1), frac_hbm_peak=round(gb / PEAK_GBS, 4))
+    wg, wu = [(torch.randn(11008, K, device="cuda") * 0.02).to(BF) for _ in range(2)]
+    ms = timeit(lambda: ops.gemv_fused(x, (wg, wu), norm_w=nw, eps=1e-5, swiglu=True), iters=50, warmup=5)
+    gb = 2 * 11008 * K * 2 / ms / 1e6
+    emit(out, kernel="gemv_fused", name="rmsnorm+gate/up+swiglu", N=11008, K=K, ms=round(ms, 4), gbs=round(gb, 1),
+         frac_hbm_peak=round(gb / PEAK_GBS, 4))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -171,7 +193,7 @@ def main():
     _lib.check("dllm_gemm_set_tile", a.tile)
     if a.out and os.path.exists(a.out):
         os.remove(a.out)
-    benches = dict(conv=bench_conv, norm=bench_norm, elementwise=bench_elementwise, attn=bench_attn, attn_bwd=bench_attn_bwd, gemm=bench_gemm)
+    benches = dict(conv=bench_conv, norm=bench_norm, elementwise=bench_elementwise, attn=bench_attn, attn_bwd=bench_attn_bwd, gemm=bench_gemm, gemv=bench_gemv)
     for name, fn in benches.items():
         if sel is None or name in sel:
             try:
