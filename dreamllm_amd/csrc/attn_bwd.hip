@@ -138,54 +138,83 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds)
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt) {
-                    const bf16x8 kf = Img::frag_row(kt_, kt * 16, ds, lane);
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s[kt][qt], 0, 0, 0);
-                }
             const bool need_mask = (kv0 + BKV > sk_len) || (CAUSAL && (kv0 + BKV - 1 > wq0 + coff));
             bf16x8 dsb[QT][2];
+            // Fragment reads run one batch of 4 ahead of the MFMAs that consume them (double-buffered registers, counted
+            // lgkmcnt from the compiler), as in the dK/dV kernel: DS steps of K row-fragments (S), 4 steps of V row-fragments
+            // (dP, softmax after each key tile), 2*DT/4 steps of K column-fragments (dQ).
+            bf16x8 fr[2][4];
+            constexpr int NA = DS, NB = 4 * (DS / 4 > 0 ? DS / 4 : 1), NC = 2 * (DT / 4);
+            static_assert(DS == 2 || DS == 4, "head dims 64 / 128");
+            constexpr int VB = DS == 4 ? 1 : 2;  // key tiles per V batch (4 fragments = VB key tiles x DS d steps)
+            constexpr int NBs = 4 / VB;          // V steps
+            auto load_step = [&](int buf, int st) {
+                if (st < NA) {  // K row-fragments of d step st, key tiles 0..3
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                f32x4 dp[QT];
+                    for (int kt = 0; kt < 4; ++kt) fr[buf][kt] = Img::frag_row(kt_, kt * 16, st, lane);
+                } else if (st < NA + NBs) {  // V row-fragments of VB key tiles, all d steps
+                    const int b0 = (st - NA) * VB;
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) dp[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int e = 0; e < 4; ++e) fr[buf][e] = Img::frag_row(vt_, (b0 + e / DS) * 16, e % DS, lane);
+                } else {  // K column-fragments: q-row half ks, d tiles 4*dq4 .. +3
+                    const int c = st - NA - NBs, ks = c / (DT / 4), dq4 = c % (DT / 4);
 #pragma unroll
-                for (int ds = 0; ds < DS; ++ds) {
-                    const bf16x8 vf = Img::frag_row(vt_, kt * 16, ds, lane);
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[qt][ds], dp[qt], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e)
+                        fr[buf][e] = Img::frag_col_rowimg(kt_, (dq4 * 4 + e) * 16, (2 * ks) * 16, (2 * ks + 1) * 16, lane);
                 }
+            };
+            constexpr int NST = NA + NBs + NC;
+            (void)NB;
+            load_step(0, 0);
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    const int qidx = wq0 + qt * 16 + t;
+            for (int st = 0; st < NST; ++st) {
+                const int buf = st & 1;
+                if (st + 1 < NST) load_step(buf ^ 1, st + 1);
+                if (st < NA) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float p = fast_exp2(fmaf(s[kt][qt][r], sl2, -lse2[qt]));
-                        if (need_mask) {
-                            const int kidx = kv0 + kt * 16 + g * 4 + r;
-                            if (kidx >= sk_len || (CAUSAL && kidx > qidx + coff)) p = 0.f;
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt)
+                            s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[buf][kt], qf[qt][st], s[kt][qt], 0, 0, 0);
+                } else if (st < NA + NBs) {
+                    const int b0 = (st - NA) * VB;
+#pragma unroll
+                    for (int vb = 0; vb < VB; ++vb) {
+                        const int kt = b0 + vb;
+                        f32x4 dp[QT];
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) dp[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int ds = 0; ds < DS; ++ds)
+#pragma unroll
+                            for (int qt = 0; qt < QT; ++qt)
+                                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[buf][vb * DS + ds], dof[qt][ds], dp[qt], 0, 0, 0);
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) {
+                            const int qidx = wq0 + qt * 16 + t;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float p = fast_exp2(fmaf(s[kt][qt][r], sl2, -lse2[qt]));
+                                if (need_mask) {
+                                    const int kidx = kv0 + kt * 16 + g * 4 + r;
+                                    if (kidx >= sk_len || (CAUSAL && kidx > qidx + coff)) p = 0.f;
+                                }
+                                if (qidx >= sq_len) p = 0.f;
+                                const float dsv = p * (dp[qt][r] - dlt[qt]);
+                                dsb[qt][kt >> 1][(kt & 1) * 4 + r] = (bf16)dsv;
+                            }
                         }
-                        if (qidx >= sq_len) p = 0.f;
-                        const float dsv = p * (dp[qt][r] - dlt[qt]);
-                        dsb[qt][kt >> 1][(kt & 1) * 4 + r] = (bf16)dsv;
                     }
+                } else {
+                    const int c = st - NA - NBs, ks = c / (DT / 4), dq4 = c % (DT / 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt)
+                            dqacc[dq4 * 4 + e][qt] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[buf][e], dsb[qt][ks], dqacc[dq4 * 4 + e][qt], 0, 0, 0);
                 }
             }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    const bf16x8 kc = Img::frag_col_rowimg(kt_, dt * 16, (2 * ks) * 16, (2 * ks + 1) * 16, lane);
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        dqacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc, dsb[qt][ks], dqacc[dt][qt], 0, 0, 0);
-                }
         }
         if (j + 1 < nblk) {
             char* nk = smem + ((j + 1) & 1) * (2 * TILE);
