@@ -305,13 +305,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
 
     TileStage<D, BQ, 256> sq, sdo;
     float stat = 0.f;
+    const uint32_t goff_q = TileStage<D, BQ, 256>::thread_goff(P.q_ss, tid);
+    const uint32_t goff_o = TileStage<D, BQ, 256>::thread_goff(P.o_ss, tid);
+    const uint32_t loff = TileStage<D, BQ, 256>::thread_loff_row(tid);
     auto gload = [&](int it) {
         const int hq = hk * group + it / nq;
         const int qb = qb_begin + it % nq;
         const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)hq * P.q_sh;
         const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)hq * P.o_sh;
-        sq.gload(qbase, P.q_ss, qb * BQ, sq_len, tid);
-        sdo.gload(dobase, P.o_ss, qb * BQ, sq_len, tid);
+        if (qb * BQ + BQ <= sq_len) {  // whole tile inside the sequence: strength-reduced addressing
+            sq.gload_full(qbase, P.q_ss, qb * BQ, goff_q);
+            sdo.gload_full(dobase, P.o_ss, qb * BQ, goff_o);
+        } else {
+            sq.gload(qbase, P.q_ss, qb * BQ, sq_len, tid);
+            sdo.gload(dobase, P.o_ss, qb * BQ, sq_len, tid);
+        }
         if (tid < 128) {
             const int qi = qb * BQ + (tid & 63);
             const float* src = (tid < 64 ? P.lse : P.delta) + ((int64_t)b * P.H + hq) * P.Sq;
@@ -320,8 +328,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
     };
     auto lstore = [&](int buf) {
         char* base = smem + buf * BUF;
-        sq.lstore_row(base, tid);
-        sdo.lstore_row(base + TILE, tid);
+        sq.lstore_row_full(base, loff);
+        sdo.lstore_row_full(base + TILE, loff);
         if (tid < 128) reinterpret_cast<float*>(base + 2 * TILE)[tid] = (tid < 64) ? stat * kLog2e : stat;
     };
 

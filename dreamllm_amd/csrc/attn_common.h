@@ -85,6 +85,30 @@ struct TileStage {
             v[p] = ld_bf16x8(base + (int64_t)row * row_stride + c * 8);
         }
     }
+    // ---- strength-reduced forms for tiles that lie fully inside the sequence (the common case) -------------------------
+    // chunk i = tid + NT*p is row (tid / CPR) + (NT / CPR) p, column chunk tid % CPR: one per-thread offset plus a uniform
+    // multiple of p.  gload_full: address = uniform base (SGPR pair) + 32-bit per-thread offset, no per-load 64-bit VALU
+    // math; lstore_row_full: LDS address = per-thread offset + immediate.  (The clamped gload above costs ~12 VALU
+    // instructions per load; the attention kernels are VALU-bound, DESIGN.md.)
+    static constexpr int RPP = NT / CPR;  // rows advanced per p
+    __device__ static __forceinline__ uint32_t thread_goff(int64_t row_stride, int tid) {
+        return (uint32_t)((tid / CPR) * row_stride + (tid % CPR) * 8);
+    }
+    __device__ static __forceinline__ uint32_t thread_loff_row(int tid) {
+        static_assert(RPP % 16 == 0, "row swizzle must not depend on p");
+        return (uint32_t)TileImg<D>::row_off(tid / CPR, tid % CPR);
+    }
+    __device__ __forceinline__ void gload_full(const bf16* base, int64_t row_stride, int row0, uint32_t goff) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const bf16* tb = base + (int64_t)(row0 + RPP * p) * row_stride;  // uniform
+            v[p] = ld_bf16x8(tb + goff);
+        }
+    }
+    __device__ __forceinline__ void lstore_row_full(char* tile, uint32_t loff) const {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x8*>(tile + loff + p * (RPP * TileImg<D>::PITCH)) = v[p];
+    }
     __device__ __forceinline__ void lstore_row(char* tile, int tid) const {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
