@@ -818,6 +818,52 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
+// ---- implicit-GEMM gather through LDS-DMA (3x3 / 1x1 NHWC convolutions on the pipelined kernel) ----------------------
+// global_load_lds takes a per-lane source address, so the im2col gather costs nothing extra: lane (row r of the DMA group,
+// 16-byte chunk c) reads channels ci..ci+7 of tap (kh, kw) of output pixel m0 + r.  Taps that fall outside the image (and
+// rows past M) read a 16-byte zero page instead.  Requires C % 64 == 0 (a 64-deep K tile never straddles two taps), plain
+// geometry (no fused upsample / transposed mode): every SD-2.1 / SDXL UNet and VAE conv except conv_in.
+__device__ __attribute__((aligned(16))) bf16 g_zero_page[8];
+
+struct ConvDma {
+    int64_t pix_off[4];   // element offset of (img, oh*stride - pad, ow*stride - pad, 0) for the lane's row in each A group
+    unsigned tapmask[4];  // bit (kh*KW + kw): that tap reads inside the image
+};
+__device__ __forceinline__ void conv_dma_init(ConvDma& d, const ConvGeom& g, int64_t m0, int64_t M, int wave, int lane) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int64_t m = m0 + (wave * 4 + q) * 8 + (lane >> 3);
+        d.pix_off[q] = 0;
+        d.tapmask[q] = 0;
+        if (m < M) {
+            const int64_t hw = (int64_t)g.OH * g.OW;
+            const int64_t img = m / hw;
+            const int rem = (int)(m - img * hw);
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+            d.pix_off[q] = img * (int64_t)g.H * g.W * g.C + ((int64_t)ih0 * g.W + iw0) * g.C;
+            unsigned mk = 0;
+            for (int kh = 0; kh < g.KH; ++kh)
+                for (int kw = 0; kw < g.KW; ++kw) {
+                    const int ih = ih0 + kh, iw = iw0 + kw;
+                    if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) mk |= 1u << (kh * g.KW + kw);
+                }
+            d.tapmask[q] = mk;
+        }
+    }
+}
+// q-th A group of the wave for the K tile that starts at channel ci0 of tap `tap` (both uniform)
+__device__ __forceinline__ void glds_conv_one(const bf16* x, const ConvGeom& g, const ConvDma& d, int tap, int ci0, char* tile,
+                                              int wave, int lane, int q) {
+    const int grp = wave * 4 + q;
+    const int r = grp * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int kh = tap / g.KW, kw = tap - kh * g.KW;
+    const bool ok = (d.tapmask[q] >> tap) & 1u;
+    const bf16* src = ok ? x + d.pix_off[q] + (int64_t)((kh * g.W + kw) * g.C + ci0 + c * 8) : g_zero_page;
+    GLDS16(src, tile + grp * 1024);
+}
+
 template <int AL, int BL>
 __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -838,7 +884,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int GROUP_M = P.group_m;
+    const int GROUP_M = P.group_m > 0 ? P.group_m : 8;
     const int in_group = GROUP_M * num_pid_n;
     const int group_id = wgid / in_group;
     const int first_m = group_id * GROUP_M;
@@ -853,13 +899,21 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    ConvDma cdma;
+    if constexpr (AL == A_CONV) conv_dma_init(cdma, P.cv, m0, P.M, wave, lane);
+    int ctap = 0, cci = 0;  // conv: tap / first channel of the K tile being prefetched (advanced incrementally: no division)
+
     auto issue = [&](int64_t k0, int buf) {
         char* ta = smem + buf * STAGE;
         char* tb = ta + TILE_BYTES;
         if constexpr (AL == A_K)
             glds_kc_tile(P.A, P.lda, m0, P.M, k0, ta, wave, lane);
-        else
+        else if constexpr (AL == A_M)
             glds_mc_tile(P.A, P.lda, m0, P.M, k0, ta, wave, lane);
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) glds_conv_one(P.A, P.cv, cdma, (int)(k0 / P.cv.C), (int)(k0 % P.cv.C), ta, wave, lane, q);
+        }
         if constexpr (BL == B_K)
             glds_kc_tile(P.B, P.ldb, n0, P.N, k0, tb, wave, lane);
         else
@@ -888,8 +942,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
         if (q < 4) {
             if constexpr (AL == A_K)
                 glds_kc_one(P.A, P.lda, m0, P.M, k0, ta, wave, lane, q);
-            else
+            else if constexpr (AL == A_M)
                 glds_mc_one(P.A, P.lda, m0, P.M, k0, ta, wave, lane, q);
+            else
+                glds_conv_one(P.A, P.cv, cdma, ctap, cci, ta, wave, lane, q);
         } else {
             if constexpr (BL == B_K)
                 glds_kc_one(P.B, P.ldb, n0, P.N, k0, tb, wave, lane, q - 4);
@@ -908,6 +964,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
         // tile t+1 goes into the buffer tile t-1 was read from: every wave finished those reads before the last barrier
         const bool pf = (t + 1 < nt) && P.dbg_noload != 1;
         const int64_t kpf = P.dbg_noload == 2 ? (int64_t)0 : (int64_t)(t + 1) * BK;
+        if constexpr (AL == A_CONV) {  // K tile t+1 starts BK channels further; wraps into the next tap at C
+            cci += BK;
+            if (cci >= P.cv.C) {
+                cci -= P.cv.C;
+                ++ctap;
+            }
+        }
         static_for<0, 16>([&](auto gc) {
             constexpr int g = decltype(gc)::value, kk = g >> 3, i = g & 7;
             if constexpr (g < 8) {  // one DMA instruction per group over the first k step: no 64-KiB burst per CU
@@ -981,10 +1044,27 @@ template <int AL, int BL>
 int launch_gemm(const GemmParams& P, hipStream_t stream) {
     if (P.M <= 0 || P.N <= 0) return DLLM_OK;
     const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);
-    const bool glds_ok = (AL != A_CONV) && g_use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K);
+    bool glds_ok = g_use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K);
+    if (AL == A_CONV)  // LDS-DMA gather: plain geometry, a K tile inside one tap, pipelined kernel only
+        glds_ok = glds_ok && g_glds_pipe && (P.cv.C % BK) == 0 && !P.cv.up_shift && !P.cv.even_only && BL == B_K;
     const bool pick256 = tile_eff(P.M, P.N, 256, glds_ok ? 1.15 : 1.0) >= tile_eff(P.M, P.N, 128, 0.85);
     if (P.splitk > 1) return launch_gemm_t<AL, BL, 128>(P, stream);
     if (g_force_tile == 256 || (g_force_tile == 0 && pick256)) {
+        if constexpr (AL == A_CONV) {
+            if constexpr (BL == B_K) {
+                if (glds_ok) {
+                    constexpr int LDS = 2 * 2 * 256 * BK * 2;
+                    static bool attr_set = false;
+                    if (!attr_set) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<AL, BL>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+                        attr_set = true;
+                    }
+                    hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);
+                    return dllm_check_launch();
+                }
+            }
+        }
         if constexpr (AL != A_CONV) {
             if (glds_ok) {
                 constexpr int LDS = 2 * 2 * 256 * BK * 2;
@@ -1130,7 +1210,8 @@ int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const 
     P.lda = C; P.ldb = P.K; P.ldc = CO; P.ldr = CO;
     P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = 0; P.alpha = 1.0f;
     P.rg_bias = (const bf16*)image_bias; P.rg_rows = (int64_t)OH * OW;
-    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace;
+    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.dbg_noload = g_dbg_noload;
+    P.group_m = g_group_m > 0 ? g_group_m : 4;  // output pixels are the M dimension (activations), as in the forward GEMMs
     P.cv = ConvGeom{H, W, C, OH, OW, KH, KW, stride, pad, up2, even_only};
     return launch_gemm<A_CONV, B_K>(P, (hipStream_t)stream);
 }

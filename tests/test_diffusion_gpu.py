@@ -30,8 +30,9 @@ def _ops():
     (2, 16, 16, 64, 64, 3, "down"), (2, 8, 8, 128, 128, 3, "up"), (1, 16, 16, 64, 64, 3, "down_asym"),
     (2, 16, 16, 4, 64, 3, "same"), (2, 16, 16, 64, 4, 3, "same"),
     (2, 8, 8, 1280, 1280, 3, "same"), (2, 16, 16, 640, 640, 3, "down"),   # small grid, deep K: split-K path
+    (4, 32, 32, 128, 256, 3, "same"), (3, 24, 40, 192, 320, 3, "same"),   # full 256-tiles: LDS-DMA gather + staged epilogue
 ])
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [128, 256, 259])
 def test_conv_fwd_dgrad(N, H, W, CI, CO, K, mode, tile):
     """Implicit-GEMM NHWC conv against F.conv2d (fp32, NCHW) incl. stride-2, fused nearest-upsample, asymmetric pad,
     channel-padded conv_in / 4-channel conv_out; input gradient through the flipped-weight conv."""
