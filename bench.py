@@ -197,21 +197,25 @@ def main():
         samples = world * a.batch * a.steps
         value = samples / dt
         achieved = gsum / tsum / 1e12 if tsum > 0 else 0.0
-        traffic = None
+        # HBM-side bytes of one launch of the dominant shape, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+        # (profiles/roofline_traffic.json; corrected as MI355X_MICROARCH.md prescribes).  A number, per launch, like `achieved`.
+        traffic, traffic_detail = None, None
         tf = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                traffic = {"hbm_bytes_per_launch": tj.get("gemm_bf16_kernel_hbm_bytes_per_launch"), "shape": tj.get("shape"),
-                           "algorithmic_bytes": tj["per_launch"]["fwd  gemm_glds_kernel<0,0>"]["algorithmic_bytes"],
-                           "source": "profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate passes)"}
+                fwd = next(v for k, v in tj["per_launch"].items() if k.startswith("fwd"))
+                traffic = int(tj.get("gemm_bf16_kernel_hbm_bytes_per_launch") or fwd["hbm_bytes_corrected"])
+                traffic_detail = {"shape": tj.get("shape"), "algorithmic_bytes": fwd["algorithmic_bytes"],
+                                  "source": "profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate "
+                                            "passes; L2->fabric requests, mostly Infinity-Cache hits)"}
             except Exception:
-                traffic = None
+                traffic, traffic_detail = None, None
         train = dict(
             value=value, ms_per_step=1e3 * dt / a.steps, loss=loss_val,
-            roofline=dict(bound="mfma", kernel="gemm_bf16_kernel (linear fwd/dgrad/wgrad + implicit-GEMM conv)",
+            roofline=dict(bound="mfma", kernel="bf16 MFMA GEMM family: gemm_pipe_kernel / gemm_bf16_kernel (linear fwd/dgrad/wgrad + implicit-GEMM conv)",
                           achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
-                          traffic=traffic, launches_per_step=len(prof) // max(a.steps, 1),
+                          traffic=traffic, traffic_detail=traffic_detail, launches_per_step=len(prof) // max(a.steps, 1),
                           avg_launch_ms=round(1e3 * tsum / max(len(prof), 1), 4),
                           time_share_of_step=round(tsum / dt, 4),
                           by_kind={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), launches=v[2] // max(a.steps, 1))
