@@ -128,7 +128,22 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const bf16* __res
         const int64_t s0 = seg_start[u], s1 = seg_start[u + 1];
         for (int v = threadIdx.x; v < vpr; v += 256) {
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int64_t j = s0; j < s1; ++j) {
+            int64_t j = s0;
+            // long segments (the <im_patch> id covers ~10^4 positions of a batch) are walked 8 rows at a time: 8 independent
+            // index loads, then 8 independent row loads in flight, summed in the original order (deterministic)
+            for (; j + 8 <= s1; j += 8) {
+                int64_t idx[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) idx[q] = order[j + q];
+                bf16x8 d[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) d[q] = ld_bf16x8(dy + idx[q] * ld_dy + v * 8);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += (float)d[q][e];
+            }
+            for (; j < s1; ++j) {
                 const bf16x8 d = ld_bf16x8(dy + order[j] * ld_dy + v * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) acc[e] += (float)d[e];

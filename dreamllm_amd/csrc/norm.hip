@@ -81,6 +81,57 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const bf16* __restrict
     }
 }
 
+// Block-per-row forward for D = 2048 * VPL and many rows (the training shapes): a row is spread over the 4 waves of a block
+// (VPL 16-byte vectors per lane instead of 8 => ~40 VGPRs instead of 151, 8 blocks per CU in flight).  The wave-per-row kernel
+// above stays in use for short inputs (decode steps), whose summation order the fused decode GEMV reproduces bit for bit.
+template <int VPL>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_block_kernel(const bf16* __restrict__ x, const bf16* __restrict__ res,
+                                                                const bf16* __restrict__ w, bf16* __restrict__ h_out,
+                                                                bf16* __restrict__ y, float* __restrict__ rstd_out, int64_t rows,
+                                                                int D, float eps) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    float v[VPL][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int64_t off = row * D + (int64_t)(tid + 256 * i) * 8;
+        const bf16x8 a = ld_bf16x8(x + off);
+        if (res != nullptr) {
+            const bf16x8 b = ld_bf16x8(res + off);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = (bf16)((float)a[j] + (float)b[j]);  // bf16 add rounds (reference: residual + hidden_states)
+                v[i][j] = (float)o[j];
+            }
+            st_bf16x8(h_out + off, o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = (float)a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)D + eps);
+    if (tid == 0 && rstd_out != nullptr) rstd_out[row] = rstd;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const bf16x8 wv = ld_bf16x8(w + (int64_t)(tid + 256 * i) * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bf16 t = (bf16)(v[i][j] * rstd);   // .to(input_dtype)
+            o[j] = (bf16)((float)wv[j] * (float)t);  // weight * (.)
+        }
+        st_bf16x8(y + row * D + (int64_t)(tid + 256 * i) * 8, o);
+    }
+}
+
 // ---------------------------------------------------------------- RMSNorm backward
 // dx = rstd * (g - xhat * mean(g * xhat)) [+ dh_in],  g = dy * w, xhat = h * rstd;  dw_partial[wave] = sum_rows dy * xhat
 template <int MAXV>
@@ -388,6 +439,18 @@ int dllm_rmsnorm_fwd(const void* x, const void* res, const void* w, void* h_out,
     if (rows == 0) return DLLM_OK;
     if (res != nullptr && h_out == nullptr) return DLLM_ERR_SHAPE;
     dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (rows >= 256 && (D % 2048) == 0 && D <= 8192) {  // training shapes: block per row
+        const dim3 g2((unsigned)rows);
+        hipStream_t s = (hipStream_t)stream;
+        const bf16 *xp = (const bf16*)x, *rp = (const bf16*)res, *wp = (const bf16*)w;
+        switch (D / 2048) {
+            case 1: hipLaunchKernelGGL(rmsnorm_fwd_block_kernel<1>, g2, block, 0, s, xp, rp, wp, (bf16*)h_out, (bf16*)y, rstd, rows, D, eps); break;
+            case 2: hipLaunchKernelGGL(rmsnorm_fwd_block_kernel<2>, g2, block, 0, s, xp, rp, wp, (bf16*)h_out, (bf16*)y, rstd, rows, D, eps); break;
+            case 3: hipLaunchKernelGGL(rmsnorm_fwd_block_kernel<3>, g2, block, 0, s, xp, rp, wp, (bf16*)h_out, (bf16*)y, rstd, rows, D, eps); break;
+            default: hipLaunchKernelGGL(rmsnorm_fwd_block_kernel<4>, g2, block, 0, s, xp, rp, wp, (bf16*)h_out, (bf16*)y, rstd, rows, D, eps); break;
+        }
+        return dllm_check_launch();
+    }
     DISPATCH_MAXV(mv, rmsnorm_fwd_kernel, grid, block, stream, (const bf16*)x,
                                           (const bf16*)res, (const bf16*)w, (bf16*)h_out, (bf16*)y, rstd, rows, D, eps);
     return dllm_check_launch();
