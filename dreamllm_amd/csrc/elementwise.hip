@@ -45,11 +45,11 @@ template <int MODE>
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
                                                       bf16* __restrict__ out, int64_t M, int F, int64_t lda, int64_t ldb,
                                                       int64_t ldo) {
+    // one block per row (grid-stride over rows), threads over the 16-byte vectors of the row: no 64-bit div/mod per vector
     const int vpr = F >> 3;
-    const int64_t total = M * vpr;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / vpr;
-        const int c = (int)(i % vpr) * 8;
+    for (int64_t r = blockIdx.x; r < M; r += gridDim.x)
+    for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
+        const int c = v * 8;
         const bf16x8 av = ld_bf16x8(a + r * lda + c), bv = ld_bf16x8(b + r * ldb + c);
         bf16x8 o;
 #pragma unroll
@@ -66,10 +66,9 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const bf16* __restrict__ d
                                                       int64_t M, int F, int64_t ldd, int64_t lda, int64_t ldb, int64_t ldda,
                                                       int64_t lddb) {
     const int vpr = F >> 3;
-    const int64_t total = M * vpr;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t r = i / vpr;
-        const int c = (int)(i % vpr) * 8;
+    for (int64_t r = blockIdx.x; r < M; r += gridDim.x)
+    for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
+        const int c = v * 8;
         const bf16x8 dv = ld_bf16x8(dout + r * ldd + c), av = ld_bf16x8(a + r * lda + c), bv = ld_bf16x8(b + r * ldb + c);
         bf16x8 oa, ob;
 #pragma unroll
@@ -454,12 +453,13 @@ int dllm_glu_fwd(const void* a, const void* b, void* out, int64_t M, int F, int6
                  void* stream) {
     if (M < 0 || F <= 0 || (F & 7) || ((lda | ldb | ldo) & 7)) return DLLM_ERR_SHAPE;
     if (M == 0) return DLLM_OK;
-    const int g = grid_for(M * (F / 8));
+    const unsigned g = (unsigned)(M < (1 << 20) ? M : (1 << 20));
+    const int vpr = F / 8, nthr = vpr >= 256 ? 256 : ((vpr + 63) / 64) * 64;  // a row's vectors on 64..256 threads
     if (mode == 0)
-        hipLaunchKernelGGL(glu_fwd_kernel<0>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b,
+        hipLaunchKernelGGL(glu_fwd_kernel<0>, dim3(g), dim3(nthr), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b,
                            (bf16*)out, M, F, lda, ldb, ldo);
     else
-        hipLaunchKernelGGL(glu_fwd_kernel<1>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b,
+        hipLaunchKernelGGL(glu_fwd_kernel<1>, dim3(g), dim3(nthr), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b,
                            (bf16*)out, M, F, lda, ldb, ldo);
     return dllm_check_launch();
 }
@@ -467,12 +467,13 @@ int dllm_glu_bwd(const void* dout, const void* a, const void* b, void* da, void*
                  int64_t ldb, int64_t ldda, int64_t lddb, int mode, void* stream) {
     if (M < 0 || F <= 0 || (F & 7) || ((ldd | lda | ldb | ldda | lddb) & 7)) return DLLM_ERR_SHAPE;
     if (M == 0) return DLLM_OK;
-    const int g = grid_for(M * (F / 8));
+    const unsigned g = (unsigned)(M < (1 << 20) ? M : (1 << 20));
+    const int vpr = F / 8, nthr = vpr >= 256 ? 256 : ((vpr + 63) / 64) * 64;
     if (mode == 0)
-        hipLaunchKernelGGL(glu_bwd_kernel<0>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, (const bf16*)a,
+        hipLaunchKernelGGL(glu_bwd_kernel<0>, dim3(g), dim3(nthr), 0, (hipStream_t)stream, (const bf16*)dout, (const bf16*)a,
                            (const bf16*)b, (bf16*)da, (bf16*)db, M, F, ldd, lda, ldb, ldda, lddb);
     else
-        hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)dout, (const bf16*)a,
+        hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3(g), dim3(nthr), 0, (hipStream_t)stream, (const bf16*)dout, (const bf16*)a,
                            (const bf16*)b, (bf16*)da, (bf16*)db, M, F, ldd, lda, ldb, ldda, lddb);
     return dllm_check_launch();
 }
