@@ -57,6 +57,22 @@ GEMM_PROFILE = None
 _GEMM_TAG = {(0, 0): "fwd", (0, 1): "dgrad", (1, 1): "wgrad", (1, 0): "tn"}
 
 
+GEMM_EVENT_POOL = []  # pre-created (and once-recorded, so the HIP event exists) timing events; see prealloc_gemm_events
+
+
+def prealloc_gemm_events(n):
+    """Create n timing events ahead of a profiled region: hipEventCreate costs ~0.2 ms, and 2 per GEMM launch inside the
+    first timed step would otherwise show up as half a second of host time in that step."""
+    for _ in range(n):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()  # torch creates the underlying event lazily at the first record
+        GEMM_EVENT_POOL.append(ev)
+
+
+def _timing_event():
+    return GEMM_EVENT_POOL.pop() if GEMM_EVENT_POOL else torch.cuda.Event(enable_timing=True)
+
+
 class _GemmTimer:
     __slots__ = ("s", "flops", "tag")
 
@@ -65,13 +81,13 @@ class _GemmTimer:
 
     def __enter__(self):
         if GEMM_PROFILE is not None:
-            self.s = torch.cuda.Event(enable_timing=True)
+            self.s = _timing_event()
             self.s.record()
         return self
 
     def __exit__(self, *a):
         if self.s is not None:
-            e = torch.cuda.Event(enable_timing=True)
+            e = _timing_event()
             e.record()
             GEMM_PROFILE.append((self.s, e, self.flops, self.tag))
         return False
