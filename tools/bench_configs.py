@@ -3,10 +3,11 @@
 
   config 2  DreamLLM-7B image-comprehension forward: prefill tokens/s (1 image -> 258 image tokens + text) and greedy
             decode tokens/s with the KV cache (batch 1: weight-bandwidth bound, 13.48 GB/token => <= ~590 tok/s at 8 TB/s)
+  config 3  SD-2.1 512 px denoise steps/s at B_img = 1 and 8 (50 DDIM steps, CFG => UNet batch 2*B_img)
   config 5  DreamLLM-SDXL stage-I step (frozen LLM fwd + dgrad-only bwd, SDXL UNet fwd + dgrad at 128x128 latents,
             196 dream queries): samples/s; plus SDXL denoise steps/s (CFG, UNet batch 2*B_img)
 
-    python tools/bench_configs.py [--only 2,5] [--out gpurun_out/configs.jsonl]
+    python tools/bench_configs.py [--only 2,3,5] [--out gpurun_out/configs.jsonl]
 Synthetic inputs, random-init weights of the named architectures; inputs resident in HBM before the timed region.
 """
 import argparse
@@ -81,6 +82,32 @@ def config2(out, a):
     torch.cuda.empty_cache()
 
 
+def config3(out, a):
+    """SD-2.1 512 px denoise loop (BASELINE config 3 / metric M2) at B_img = 1 and 8: 50 deterministic DDIM steps, CFG 7.5
+    => one UNet forward at batch 2*B_img per step.  Only the head is built (UNet + VAE + projector)."""
+    from dreamllm_amd.modeling_plugins import StableDiffusionHead
+    from dreamllm_amd.schedulers import DDIMScheduler
+    torch.manual_seed(0)
+    head = StableDiffusionHead("sd21-base", embed_hidden_size=4096).to("cuda", BF).eval()
+    steps = 50
+    for Bi in (1, 8):
+        g = torch.Generator().manual_seed(42)
+        pe = (torch.randn(Bi, 64, 4096, generator=g) * 0.02).to("cuda", BF)
+        ne = (torch.randn(Bi, 64, 4096, generator=g) * 0.02).to("cuda", BF)
+        kw = dict(guidance_scale=7.5, prompt_embeds=pe, negative_prompt_embeds=ne, output_type="latent", scheduler=DDIMScheduler())
+        head.pipeline(num_inference_steps=2, generator=torch.Generator().manual_seed(42), **kw)  # warm-up + graph capture
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        head.pipeline(num_inference_steps=steps, generator=torch.Generator().manual_seed(42), **kw)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        emit(out, config=3, metric="SD-2.1 512px denoise steps/s (50 DDIM eta=0, CFG 7.5)", value=round(steps / t, 2), unit="steps/s",
+             batch_images=Bi, unet_batch=2 * Bi, ms_per_step=round(t / steps * 1e3, 3),
+             frac_mfma_peak=round(steps / t * 2 * Bi * 0.803e12 / 1e12 / PEAK_TF, 4), dtype="bf16", data="synthetic")
+    del head
+    torch.cuda.empty_cache()
+
+
 def config5(out, a):
     from dreamllm_amd.factory import build_dreamllm_sdxl
     from dreamllm_amd.optim import HipAdamW
@@ -127,7 +154,7 @@ def config5(out, a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="2,5")
+    ap.add_argument("--only", default="2,3,5")
     ap.add_argument("--out", default="")
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--prompt-len", type=int, default=448)
@@ -143,6 +170,8 @@ def main():
     sel = set(a.only.split(","))
     if "2" in sel:
         config2(a.out, a)
+    if "3" in sel:
+        config3(a.out, a)
     if "5" in sel:
         config5(a.out, a)
 
