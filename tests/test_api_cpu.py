@@ -140,3 +140,34 @@ def test_synthetic_batch_layout_and_slot_indices():
     assert (ids.view(-1)[di] == sp["<im_patch>"]).all() and (ids.view(-1)[ii + 16 - 15 * 0][-1] != -1)
     full = make_interleaved_batch(2, 2048, 2, with_pixels=False)
     assert full["attention_mask"].all() and full["dream_index"].numel() == 2 * 2 * 64 and full["image_index"].numel() == 2 * 2 * 256
+
+
+def test_sdxl_model_classes_and_creation_batch():
+    """DreamLLM-SDXL host side (omni/models/dreamllm_sdxl/*): 8 additional special tokens with <dream_patch> between <dream>
+    and <dream_start> (vocab 32009), class names, non-persistent inv_freq, stage-I freeze policy, creation-only batch layout."""
+    from dreamllm_amd.factory import build_dreamllm_sdxl
+    from dreamllm_amd.modeling_dreamllm_sdxl import (DreamLLMSDXLConfig, DreamLLMSDXLForCausalMLM, DreamLLMSDXLModel,
+                                                      additional_special_tokens, default_special_tokens2ids)
+    from dreamllm_amd.synthetic import make_creation_batch
+    ids = default_special_tokens2ids(32000)
+    add = ids["additional_special_tokens"]
+    assert additional_special_tokens.index("<dream_patch>") == additional_special_tokens.index("<dream>") + 1
+    assert add["<dream_patch>"] == 32006 and add["<dream_start>"] == 32007 and add["<dream_end>"] == 32008 and ids["[PAD]"] == 32000
+    sd = dict(unet=unet_ref.tiny_config(64, sdxl=True), vae=dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1))
+    m = build_dreamllm_sdxl(TINY, device="cpu", dtype=torch.float32, with_clip=False, diffusion=sd, num_dream_queries=8,
+                            global_condition_hidden_size=40)
+    assert isinstance(m, DreamLLMSDXLForCausalMLM) and isinstance(m.model, DreamLLMSDXLModel) and isinstance(m.config, DreamLLMSDXLConfig)
+    assert m.config.vocab_size == 32009 and m.lm_head.weight.shape[0] == 32009
+    assert m._dream_patch_token == "<dream_patch>" and m._loss_scale_twice
+    assert not any("inv_freq" in k for k in m.state_dict())
+    assert sorted(n for n, p in m.named_parameters() if p.requires_grad) == [
+        "model.dream_embedding.dream_queries", "stable_diffusion_head.global_projector.projector.weight",
+        "stable_diffusion_head.projector.projector.weight"]
+    assert (m.config.loss_weight_lm, m.config.loss_weight_vm) == (0.0, 1.0)
+    b = make_creation_batch(batch_size=3, seq_len=32, n_dream=8, with_pixels=False)
+    ii = b["input_ids"]
+    assert ii.shape == (3, 32) and (ii[:, 0] == 1).all() and (ii[:, -1] == 2).all()
+    assert (ii == add["<dream_patch>"]).sum() == 3 * 8 and (ii == add["<dream_start>"]).sum() == 3
+    di, _ = _slot_indices(ii, add["<dream_start>"], 8)
+    assert torch.equal(di, b["dream_index"])
+    assert (b["labels"][ii == add["<dream_patch>"]] == -100).all() and (b["labels"][ii == add["<dream_end>"]] == -100).all()
