@@ -300,3 +300,56 @@ print("COMPILE_OK")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                        cwd=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
     assert "COMPILE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+class _FakeXLHead(nn.Module):
+    """the fake head of oracle/make_golden_sdxl.py (drop_prob set => the model must run the unconditional pass)"""
+    drop_prob = 0.1
+
+    def forward(self, images, encoder_hidden_states, u=None, add_time_ids=None, dream_embeddings=None):
+        if images is None:
+            assert add_time_ids is None
+            return (0.0 * dream_embeddings).sum()
+        t = (add_time_ids.float() / 100.0).sum(-1)[:, None, None]
+        return ((encoder_hidden_states.float() * images.float()).pow(2) * t).mean() + 0.5 * (u.float() * images.float()).pow(2).mean()
+
+
+class _NoClip(nn.Module):
+    embed_len = 6
+
+    def forward(self, images=None):
+        return torch.zeros((), device=DEV)
+
+
+def test_causal_mlm_sdxl_golden(golden):
+    """DreamLLMSDXLForCausalMLM against the EXECUTED reference (omni/models/dreamllm_sdxl/modeling_dreamllm_sdxl.py, fixture
+    from oracle/make_golden_sdxl.py): add_time_ids handed to the head, unconditional pass over <dream_patch> tokens
+    (head.drop_prob set), loss divided by loss_scale twice (l1_norm schedule => /16), dummy branch, no inv_freq keys."""
+    from dreamllm_amd.modeling_dreamllm_sdxl import DreamLLMSDXLConfig, DreamLLMSDXLForCausalMLM
+    from oracle.make_golden_sdxl import special_tokens2ids_dict
+    g = golden("causal_mlm_sdxl.pt")
+    cd = g["cfg"]
+    cfg = DreamLLMSDXLConfig(vocab_size=cd["vocab_size"], hidden_size=cd["hidden_size"], intermediate_size=cd["intermediate_size"],
+                             num_hidden_layers=cd["num_hidden_layers"], num_attention_heads=cd["num_attention_heads"],
+                             rms_norm_eps=cd["rms_norm_eps"], max_position_embeddings=cd["max_position_embeddings"],
+                             special_tokens2ids_dict=special_tokens2ids_dict(), loss_weight_lm=g["loss_weight_lm"],
+                             loss_weight_vm=g["loss_weight_vm"], loss_scale_schedule=g["loss_scale_schedule"])
+    lm = DreamLLMSDXLForCausalMLM(cfg)
+    lm.model.dream_embedding = _FakeDream(cd["hidden_size"])
+    lm.model.clip_vision_embedding = _NoClip()
+    lm.stable_diffusion_head = _FakeXLHead()
+    res = lm.load_state_dict(g["sd"], strict=False)
+    assert not res.unexpected_keys and not res.missing_keys, (res.unexpected_keys, res.missing_keys)  # no inv_freq either side
+    lm = lm.to(DEV, BF).train()
+    kw = dict(input_ids=g["input_ids"].to(DEV), attention_mask=g["attention_mask"].to(DEV), labels=g["labels"].to(DEV), return_dict=True)
+    out = lm(images_dm=g["images_dm"].to(BF).to(DEV), add_time_ids=g["add_time_ids"].to(DEV), **kw)
+    out.loss.backward()
+    assert rel_l2(out.logits, g["logits"]) <= 2.5e-2
+    assert abs(float(out.additional_log_info["lm_loss"]) - float(g["lm_loss"])) <= 5e-3 * abs(float(g["lm_loss"]))
+    assert abs(float(out.additional_log_info["vm_loss"]) - float(g["vm_loss"])) <= 4e-2 * abs(float(g["vm_loss"]))
+    assert abs(out.loss.item() - g["loss"].item()) <= 1.5e-2 * abs(g["loss"].item())   # (3 vm + lm) / 4 / 4
+    assert rel_l2(lm.model.dream_embedding.dream_queries.grad, g["grad_dream"]) <= 5e-2
+    assert rel_l2(lm.model.layers[0].self_attn.q_proj.weight.grad, g["grad_q0"].float()) <= 6e-2
+    lm.zero_grad(set_to_none=True)
+    out2 = lm(images_dm=None, add_time_ids=None, **kw)
+    assert abs(out2.loss.item() - g["loss_dummy"].item()) <= 1e-2 * abs(g["loss_dummy"].item())
