@@ -81,7 +81,11 @@ int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const 
                                  const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                                  int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,
                                  float* workspace, void* stream);
-/* tile-size override for tests / microbenchmarks: 0 automatic, 128 or 256 (process-global) */
+/* Kernel-variant override for tests / microbenchmarks ONLY (process-global, not thread-safe; the product path never calls it):
+ * 0 automatic; 128 / 256 register-staged tiles; 257 plain LDS-DMA 256-tile kernel; 259 software-pipelined LDS-DMA kernel (the
+ * default for eligible shapes); 258 / 260 the same without K-loop prefetches, 263 every prefetch re-reads K tile 0, 265 no C
+ * stores (these three give wrong results by design: they bracket the cost of the memory path); 1000 + g sets GROUP_M = g of
+ * the grouped tile order (1000 restores the per-layout default).  Returns DLLM_ERR_SHAPE for anything else. */
 int dllm_gemm_set_tile(int tile);
 /* NHWC convolution (3x3 / 1x1) as implicit GEMM: ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D, Upsample2D,
  * conv_in/conv_out of UNet2DConditionModel and AutoencoderKL [ext] (call sites modeling_plugins.py:511,556,815-821,842).
