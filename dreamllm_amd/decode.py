@@ -114,13 +114,14 @@ class GreedyDecodeSession:
         self.slot.copy_(torch.arange(B, device=self.tok.device) * self.max_len + S)
         self.step_idx.zero_()
         self.prompt_len = S
+        self.generated = 0  # tokens produced by generate() since this prefill (host-side count of graph replays)
         self.first = first
         return first
 
     @torch.no_grad()
     def generate(self, n_more: int):
-        """n_more further tokens after the one `prefill` produced; returns [B, n_more]."""
-        if self.prompt_len + 1 + n_more > self.max_len:
+        """n_more further tokens after those already produced since `prefill`; returns [B, n_more] (may be called repeatedly)."""
+        if self.prompt_len + 1 + self.generated + n_more > self.max_len:
             raise ValueError("generation would overflow the KV cache")
         if n_more <= 0:
             return self.out_tokens[:0].t()
@@ -143,4 +144,6 @@ class GreedyDecodeSession:
                 self.graph.replay()
             else:
                 self.logits = self._token_step()
-        return self.out_tokens[:n_more].t().contiguous()
+        start = self.generated
+        self.generated += n_more
+        return self.out_tokens[start:start + n_more].t().contiguous()

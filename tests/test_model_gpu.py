@@ -204,11 +204,12 @@ def test_decode_session_matches_model_forward_logits():
     seq = torch.cat([ids, first[:, None]], 1)
     toks = []
     for _ in range(6):
-        nxt = sess.generate(1)  # NB: out_tokens row 0 is rewritten per call only after a new prefill; read the logits
+        nxt = sess.generate(1)
         with torch.no_grad():
             full = lm(input_ids=seq, return_dict=True).logits[:, -1]
         assert rel_l2(sess.logits, full) < 2e-2
         tok = sess.logits.argmax(-1)
+        assert torch.equal(nxt[:, 0], tok)  # repeated generate() calls continue where the previous one stopped
         top2 = full.float().topk(2, dim=-1).values
         clear = (top2[:, 0] - top2[:, 1]) > 0.05
         assert torch.equal(tok[clear], full.argmax(-1)[clear])
