@@ -19,6 +19,7 @@ from torch import nn
 
 from . import ops
 from .projector import build_projector
+from . import utils as _u
 from .utils import FSDPMixin, check_path_and_file, get_model_device, get_model_dtype, logger, randn_tensor
 
 PluginType = Literal["embedding", "head"]
@@ -376,6 +377,28 @@ class StableDiffusionHead(MultimodalHead):
         sigma = ((1.0 - ac) ** 0.5)[timesteps].float()
         return (alpha / sigma) ** 2
 
+    def _noised_latents(self, images, encoder_hidden_states, noise=None, timesteps=None):
+        """modeling_plugins.py:510-536: VAE-encode (sampled), scale, draw noise (+offset, +perturbation) and timesteps, add
+        noise.  The random numbers are drawn in the reference's order: VAE sample, noise, offset, perturbation, timesteps."""
+        with torch.no_grad():
+            dist = self.vae.encode(images.to(self.dtype))
+            latents = dist.sample(noise=_u.draws.randn(dist.mean.shape, device=dist.mean.device, dtype=dist.mean.dtype))
+            latents = latents * self.vae.config.scaling_factor
+        assert (
+            encoder_hidden_states.shape[0] == latents.shape[0]
+        ), f"encoder_hidden_states.shape[0]: {encoder_hidden_states.shape[0]} != latents.shape[0]: {latents.shape[0]}"
+        bsz = latents.shape[0]
+        if noise is None:
+            noise = _u.draws.randn_like(latents)
+        if self.noise_offset:
+            noise = noise + self.noise_offset * _u.draws.randn((bsz, latents.shape[1], 1, 1), device=latents.device,
+                                                              dtype=latents.dtype)
+        new_noise = noise + self.input_perturbation * _u.draws.randn_like(noise) if self.input_perturbation else noise
+        if timesteps is None:
+            timesteps = _u.draws.randint(0, self.noise_scheduler.config.num_train_timesteps, (bsz,), device=latents.device)
+        timesteps = timesteps.long()
+        return latents, noise, timesteps, self.noise_scheduler.add_noise(latents, new_noise, timesteps)
+
     def forward(self, images=None, encoder_hidden_states=None, u_encoder_hidden_states=None, dream_embeddings=None,
                 noise=None, timesteps=None):
         """modeling_plugins.py:493-577.  `noise` / `timesteps` may be injected (tests, reproducible benchmarks); when
@@ -387,25 +410,11 @@ class StableDiffusionHead(MultimodalHead):
             dummy = self.projector(dummy)[-1]
             return (0.0 * dummy).sum() + (0.0 * dream_embeddings).sum()
 
-        with torch.no_grad():
-            latents = self.vae.encode(images.to(self.dtype)).sample() * self.vae.config.scaling_factor
-        assert (
-            encoder_hidden_states.shape[0] == latents.shape[0]
-        ), f"encoder_hidden_states.shape[0]: {encoder_hidden_states.shape[0]} != latents.shape[0]: {latents.shape[0]}"
+        latents, noise, timesteps, noisy_latents = self._noised_latents(images, encoder_hidden_states, noise, timesteps)
         bsz = latents.shape[0]
-        if noise is None:
-            noise = torch.randn_like(latents)
-        if self.noise_offset:
-            noise = noise + self.noise_offset * torch.randn((bsz, latents.shape[1], 1, 1), device=latents.device,
-                                                            dtype=latents.dtype)
-        new_noise = noise + self.input_perturbation * torch.randn_like(noise) if self.input_perturbation else noise
-        if timesteps is None:
-            timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (bsz,), device=latents.device)
-        timesteps = timesteps.long()
-        noisy_latents = self.noise_scheduler.add_noise(latents, new_noise, timesteps)
 
         if u_encoder_hidden_states is not None and self.drop_prob is not None:
-            mask = torch.bernoulli(torch.zeros(bsz) + self.drop_prob).to(latents.device)[:, None, None]
+            mask = _u.draws.bernoulli(torch.zeros(bsz) + self.drop_prob).to(latents.device)[:, None, None]
             mask = mask.to(encoder_hidden_states.dtype)
             encoder_hidden_states = (1.0 - mask) * encoder_hidden_states + mask * u_encoder_hidden_states
 

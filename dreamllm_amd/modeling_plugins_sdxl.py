@@ -154,22 +154,8 @@ class StableDiffusionXLHead(StableDiffusionHead):
             dummy_global = self.global_projector(dummy.mean(1))[-1]
             return (0.0 * dummy_local).sum() + (0.0 * dummy_global).sum() + (0.0 * dream_embeddings).sum()
 
-        with torch.no_grad():
-            latents = self.vae.encode(images.to(self.dtype)).sample() * self.vae.config.scaling_factor
-        assert (
-            encoder_hidden_states.shape[0] == latents.shape[0]
-        ), f"encoder_hidden_states.shape[0]: {encoder_hidden_states.shape[0]} != latents.shape[0]: {latents.shape[0]}"
+        latents, noise, timesteps, noisy_latents = self._noised_latents(images, encoder_hidden_states, noise, timesteps)
         bsz = latents.shape[0]
-        if noise is None:
-            noise = torch.randn_like(latents)
-        if self.noise_offset:
-            noise = noise + self.noise_offset * torch.randn((bsz, latents.shape[1], 1, 1), device=latents.device,
-                                                            dtype=latents.dtype)
-        new_noise = noise + self.input_perturbation * torch.randn_like(noise) if self.input_perturbation else noise
-        if timesteps is None:
-            timesteps = torch.randint(0, self.noise_scheduler.config.num_train_timesteps, (bsz,), device=latents.device)
-        timesteps = timesteps.long()
-        noisy_latents = self.noise_scheduler.add_noise(latents, new_noise, timesteps)
 
         global_states = encoder_hidden_states.mean(1)  # [N, D]: mean over the dream queries (:198); tiny, stays in torch
         global_states = self.global_projector(global_states)[-1]

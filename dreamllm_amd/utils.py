@@ -39,6 +39,77 @@ def check_path_and_file(path, file):
     return False
 
 
+class _TorchDraws:
+    """Where the plugin heads get their random numbers (`torch.randn / randn_like / randint / bernoulli`, called exactly
+    where the reference calls them: modeling_plugins.py:511,520-528,541).  One indirection so that tests can replay the
+    draws recorded from an execution of the reference wrapper (`replay_draws`)."""
+
+    def randn(self, shape, generator=None, device=None, dtype=None):
+        return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+
+    def randn_like(self, x):
+        return torch.randn_like(x)
+
+    def randint(self, low, high, shape, device=None):
+        return torch.randint(low, high, shape, device=device)
+
+    def bernoulli(self, p):
+        return torch.bernoulli(p)
+
+
+class _ReplayDraws:
+    """Returns pre-recorded draws in order (kind and shape are checked); see oracle/duck_diffusers.DrawLog."""
+
+    def __init__(self, draws):
+        self._q = list(draws)
+
+    def _next(self, kind, shape, device, dtype):
+        if not self._q:
+            raise AssertionError(f"replay_draws: no recorded draw left for {kind}{tuple(shape)}")
+        k, t = self._q.pop(0)
+        if k != kind or tuple(t.shape) != tuple(shape):
+            raise AssertionError(f"replay_draws: expected {k}{tuple(t.shape)}, the head asked for {kind}{tuple(shape)}")
+        return t.to(device=device, dtype=dtype if dtype is not None else t.dtype)
+
+    def randn(self, shape, generator=None, device=None, dtype=None):
+        return self._next("randn", shape, device, dtype)
+
+    def randn_like(self, x):
+        return self._next("randn_like", x.shape, x.device, x.dtype)
+
+    def randint(self, low, high, shape, device=None):
+        return self._next("randint", shape, device, torch.int64)
+
+    def bernoulli(self, p):
+        return self._next("bernoulli", p.shape, p.device, p.dtype)
+
+    def remaining(self):
+        return len(self._q)
+
+
+draws = _TorchDraws()
+
+
+class replay_draws:
+    """`with replay_draws(recorded): head(...)` -- the heads consume `recorded` instead of fresh random numbers."""
+
+    def __init__(self, recorded):
+        self._src = _ReplayDraws(recorded)
+
+    def __enter__(self):
+        global draws
+        self._prev = draws
+        draws = self._src
+        return self._src
+
+    def __exit__(self, *exc):
+        global draws
+        draws = self._prev
+        if exc[0] is None and self._src.remaining():
+            raise AssertionError(f"replay_draws: {self._src.remaining()} recorded draws were not consumed")
+        return False
+
+
 def randn_tensor(shape, generator=None, device=None, dtype=None):
     """omni/utils/torch_utils.py:7-52: sample on the generator's device (CPU generator => CPU sample, then moved) so a
     seed reproduces the same latents on every backend."""
@@ -49,8 +120,8 @@ def randn_tensor(shape, generator=None, device=None, dtype=None):
         return torch.cat(lat, 0)
     gdev = generator.device.type if generator is not None else torch.device(device).type
     if gdev == "cpu":
-        return torch.randn(shape, generator=generator, device="cpu", dtype=dtype).to(device)
-    return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+        return draws.randn(shape, generator=generator, device="cpu", dtype=dtype).to(device)
+    return draws.randn(shape, generator=generator, device=device, dtype=dtype)
 
 
 def locate(name: str):

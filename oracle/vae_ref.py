@@ -73,3 +73,76 @@ def decode(z, sd, cfg):
                          sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"], padding=1)
     x = F.silu(F.group_norm(x, g, sd["decoder.conv_norm_out.weight"], sd["decoder.conv_norm_out.bias"], 1e-6))
     return F.conv2d(x, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+
+
+def param_shapes(cfg):
+    """name -> shape of every AutoencoderKL parameter (diffusers >= 0.18 key names) for the given config."""
+    boc, lpb = tuple(cfg["block_out_channels"]), cfg["layers_per_block"]
+    L, cin, cout = cfg.get("latent_channels", 4), cfg.get("in_channels", 3), cfg.get("out_channels", 3)
+    sh = {}
+
+    def conv(p, i, o, k):
+        sh[p + ".weight"], sh[p + ".bias"] = (o, i, k, k), (o,)
+
+    def lin(p, i, o):
+        sh[p + ".weight"], sh[p + ".bias"] = (o, i), (o,)
+
+    def norm(p, c):
+        sh[p + ".weight"], sh[p + ".bias"] = (c,), (c,)
+
+    def res(p, i, o):
+        norm(p + ".norm1", i)
+        conv(p + ".conv1", i, o, 3)
+        norm(p + ".norm2", o)
+        conv(p + ".conv2", o, o, 3)
+        if i != o:
+            conv(p + ".conv_shortcut", i, o, 1)
+
+    def mid(p, c):
+        res(p + ".resnets.0", c, c)
+        norm(p + ".attentions.0.group_norm", c)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            lin(p + ".attentions.0." + n, c, c)
+        res(p + ".resnets.1", c, c)
+
+    conv("encoder.conv_in", cin, boc[0], 3)
+    c = boc[0]
+    for i, o in enumerate(boc):
+        for j in range(lpb):
+            res(f"encoder.down_blocks.{i}.resnets.{j}", c if j == 0 else o, o)
+        if i < len(boc) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", o, o, 3)
+        c = o
+    mid("encoder.mid_block", boc[-1])
+    norm("encoder.conv_norm_out", boc[-1])
+    conv("encoder.conv_out", boc[-1], 2 * L, 3)
+    conv("quant_conv", 2 * L, 2 * L, 1)
+    conv("post_quant_conv", L, L, 1)
+    rev = boc[::-1]
+    conv("decoder.conv_in", L, rev[0], 3)
+    mid("decoder.mid_block", rev[0])
+    c = rev[0]
+    for i, o in enumerate(rev):
+        for j in range(lpb + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", c if j == 0 else o, o)
+        if i < len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", o, o, 3)
+        c = o
+    norm("decoder.conv_norm_out", boc[0])
+    conv("decoder.conv_out", boc[0], cout, 3)
+    return sh
+
+
+def random_state_dict(cfg, seed=0, dtype=torch.float32):
+    """Seeded default-PyTorch-like init (uniform +-1/sqrt(fan_in)), norm weights around 1 -- reproducible on any host."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, s in param_shapes(cfg).items():
+        if "norm" in k:
+            t = (1.0 + 0.1 * torch.randn(s, generator=g)) if k.endswith("weight") else 0.1 * torch.randn(s, generator=g)
+        elif k.endswith(".weight"):
+            t = (torch.rand(s, generator=g) * 2 - 1) / math.sqrt(math.prod(s[1:]))
+        else:
+            t = (torch.rand(s, generator=g) * 2 - 1) * 0.05
+        sd[k] = t.to(dtype)
+    return sd

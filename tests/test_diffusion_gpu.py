@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l2
+from conftest import check_scalar, check_tensor, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -179,18 +179,18 @@ def test_unet_forward_and_context_gradient(sdxl):
     yr = unet_ref.unet_forward(x, t, cr, sd, cfg, added)
     dy = bf16r(torch.randn_like(yr))
     yr.backward(dy)
-    with torch.no_grad():
-        yb = unet_ref.unet_forward(x.to(BF), t, ctx.to(BF), {k: v.to(BF) for k, v in sd.items()}, cfg,
-                                   None if added is None else {k: v.to(BF) for k, v in added.items()})
+    cb = ctx.to(BF).requires_grad_(True)  # the oracle itself in bf16: forward AND context gradient yard-sticks
+    yb = unet_ref.unet_forward(x.to(BF), t, cb, {k: v.to(BF) for k, v in sd.items()}, cfg,
+                               None if added is None else {k: v.to(BF) for k, v in added.items()})
+    yb.backward(dy.to(BF))
     e_ref = rel_l2(yb, yr)
     cd = ctx.to(BF).to(DEV).requires_grad_(True)
     addd = None if added is None else {k: v.to(DEV) for k, v in added.items()}
     y = m(x.to(BF).to(DEV), t.to(DEV), cd, added_cond_kwargs=addd).sample
     assert y.shape == yr.shape
-    e = rel_l2(y, yr)
-    assert e <= 1.5 * e_ref + 2e-3, (e, e_ref)
+    check_tensor(f"unet{'_xl' if sdxl else ''}.forward", y, yr, e_ref)
     y.backward(dy.to(BF).to(DEV))
-    assert rel_l2(cd.grad, cr.grad) <= 4e-2
+    check_tensor(f"unet{'_xl' if sdxl else ''}.grad_ctx", cd.grad, cr.grad, rel_l2(cb.grad, cr.grad))
 
 
 def test_unet_context_cache_matches():
@@ -236,147 +236,123 @@ def test_vae_encode_decode():
     assert rel_l2(v.decode(z.to(DEV)), dec) <= 1.5 * e_dec + 2e-3
 
 
-# ----------------------------------------------------------------------------- StableDiffusionHead
-def _tiny_head(embed=128):
+# ----------------------------------------------------------------------------- StableDiffusionHead / StableDiffusionXLHead
+# Fixtures tests/golden/{sd_head,sdxl_head}.pt come from EXECUTING the reference wrappers (oracle/make_golden_sdhead.py:
+# the real `StableDiffusionHead.forward/pipeline`, `_compute_snr`, `_rescale_noise_cfg` and the SDXL overrides, with the
+# restated diffusers UNet/VAE/schedulers attached).  The HIP heads replay the random draws the reference consumed, in the
+# reference's order, and are held to the tolerance contract against the fp32 run with the reference's own bf16 run as err_ref.
+_FWD_CASES = {False: ["plain", "offset_perturb_snr", "v_prediction_snr", "cfg_drop"],
+              True: ["plain", "offset_perturb_snr", "v_prediction_snr"]}
+_PIPE_CASES = {False: ["ddim_1", "ddim_10", "ddim_50", "ddim_10_rescale", "ddim_4_nocfg", "ddpm_10", "ddpm_5_pt_randlat",
+                       "ddim_4_vpred_eta"],
+               True: ["ddim_1", "ddim_10", "ddim_50", "ddim_10_rescale", "ddim_4_nocfg", "ddpm_10", "ddpm_5_pt_randlat",
+                      "ddim_4_vpred_eta", "ddim_4_microcond"]}
+
+
+def _fixture_head(g, xl, prediction_type="epsilon", **knobs):
+    """The HIP head on the fixture's tiny config with the seeded weights the reference run used."""
     from dreamllm_amd.modeling_plugins import StableDiffusionHead
-    from oracle import unet_ref
-    ucfg = unet_ref.tiny_config(cross_dim=64)
-    torch.manual_seed(4)
-    head = StableDiffusionHead(dict(unet=ucfg, vae=dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1)),
-                               embed_hidden_size=embed)
-    usd = {k: bf16r(v) for k, v in unet_ref.random_state_dict(ucfg, seed=1).items()}
-    head.unet.load_state_dict(usd)
-    for p in head.parameters():
-        p.data = bf16r(p.data)
-    return head, ucfg, usd
+    from dreamllm_amd.modeling_plugins_sdxl import StableDiffusionXLHead
+    from oracle import unet_ref, vae_ref
+    from oracle.make_golden_sdhead import projector_weights
+    ucfg, vcfg, seeds = g["unet_cfg"], g["vae_cfg"], g["seeds"]
+    spec = dict(unet=ucfg, vae=vcfg, scheduler=dict(prediction_type=prediction_type))
+    if xl:
+        head = StableDiffusionXLHead(spec, embed_hidden_size=g["embed"], global_condition_hidden_size=g["gdim"], **knobs)
+    else:
+        head = StableDiffusionHead(spec, embed_hidden_size=g["embed"], **knobs)
+    head.unet.load_state_dict({k: bf16r(v) for k, v in unet_ref.random_state_dict(ucfg, seed=seeds["unet"]).items()})
+    head.vae.load_state_dict({k: bf16r(v) for k, v in vae_ref.random_state_dict(vcfg, seed=seeds["vae"]).items()})
+    pw = projector_weights(ucfg["cross_attention_dim"], xl)
+    head.projector.projector.weight.data = pw["projector"].clone()
+    if xl:
+        head.global_projector.projector.weight.data = pw["global_projector"].clone()
+    assert abs(head.vae.config.scaling_factor - vcfg["scaling_factor"]) < 1e-12
+    return head.to(DEV, BF)
 
 
-def test_sd_head_training_loss_and_grad():
-    """StableDiffusionHead.forward (modeling_plugins.py:493-577) with injected noise/timesteps: VAE-encode -> add_noise ->
-    projector -> UNet -> MSE; loss and d(loss)/d(dream states) against the oracles."""
-    from oracle import unet_ref, vae_ref, sched_ref
-    head, ucfg, usd = _tiny_head()
-    vsd = {k: v.clone() for k, v in head.vae.state_dict().items()}
-    pw = head.projector.projector.weight.data.clone()
-    N = 2
-    img = bf16r(torch.rand(N, 3, 128, 128) * 2 - 1)
-    enc = bf16r(torch.randn(N, 8, 128) * 0.5)
-    noise = bf16r(torch.randn(N, 4, 16, 16))
-    ts = torch.tensor([100, 700])
-    head = head.to(DEV, BF)
-    encd = enc.to(BF).to(DEV).requires_grad_(True)
-    # the VAE sample uses torch.randn inside: fix it by seeding and mirroring on the oracle side through the mean (std ~ small)
-    torch.manual_seed(9)
-    loss = head(img.to(DEV), encd, None, None, noise=noise.to(DEV), timesteps=ts.to(DEV))
+def _case(g, kind, name):
+    return next(c for c in g[kind] if c["name"] == name)
+
+
+@pytest.mark.parametrize("xl,name", [(xl, n) for xl in (False, True) for n in _FWD_CASES[xl]])
+def test_sd_head_forward_vs_executed_reference(golden, xl, name):
+    """`StableDiffusion(XL)Head.forward` (modeling_plugins.py:493-577, dreamllm_sdxl :151-236) against the executed reference:
+    noise offset + input perturbation + min-SNR weights, v-prediction target, CFG-drop mixing, SDXL global projector /
+    add_time_ids; loss and the gradients of the dream states, the unconditional states and the projector(s)."""
+    from dreamllm_amd.utils import replay_draws
+    tag = "sdxl_head" if xl else "sd_head"
+    g = golden(tag + ".pt")
+    c = _case(g, "forward", name)
+    head = _fixture_head(g, xl, prediction_type=c["prediction_type"], **c["knobs"])
+    inp = c["inputs"]
+    enc = inp["enc"].to(BF).to(DEV).requires_grad_(True)
+    u = inp["u_enc"].to(BF).to(DEV).requires_grad_(True) if "u_enc" in inp else None
+    with replay_draws(c["draws"]):
+        if xl:
+            loss = head(inp["images"].to(DEV), enc, u, inp["add_time_ids"].to(DEV), None)
+        else:
+            loss = head(inp["images"].to(DEV), enc, u, None)
     loss.backward()
-    # oracle: same latents (take them from the HIP VAE mean/std with the same RNG draw replaced by the mode for stability)
-    vcfg = dict(head.vae.config.to_dict())
-    mom = vae_ref.encode_moments(img, vsd, vcfg)
-    torch.manual_seed(9)
-    eps_v = torch.randn(mom[:, :4].shape, device=DEV).cpu()
-    lat = vae_ref.sample_latents(mom, eps_v, vcfg["scaling_factor"])
-    ac = sched_ref.alphas_cumprod()
-    noisy = torch.stack([sched_ref.add_noise(lat[i], noise[i], int(ts[i]), ac) for i in range(N)])
-    er = enc.clone().requires_grad_(True)
-    pred = unet_ref.unet_forward(noisy, ts, F.linear(er, pw), usd, ucfg)
-    lref = F.mse_loss(pred.float(), noise.float())
-    lref.backward()
-    assert abs(loss.item() - lref.item()) <= 2e-2 * abs(lref.item()), (loss.item(), lref.item())
-    assert rel_l2(encd.grad, er.grad) <= 6e-2
-    assert rel_l2(head.projector.projector.weight.grad, torch.autograd.grad(
-        F.mse_loss(unet_ref.unet_forward(noisy, ts, F.linear(enc, pw.requires_grad_(True)), usd, ucfg).float(), noise.float()),
-        pw)[0]) <= 6e-2
+    pre = f"{tag}.forward.{name}."
+    check_scalar(pre + "loss", loss, c["loss"], abs(float(c["loss_bf16"]) - float(c["loss"])))
+    check_tensor(pre + "grad_enc", enc.grad, c["grad_enc"].float(), rel_l2(c["grad_enc_bf16"].float(), c["grad_enc"].float()))
+    check_tensor(pre + "grad_projector", head.projector.projector.weight.grad, c["grad_projector"].float(),
+                 rel_l2(c["grad_projector_bf16"].float(), c["grad_projector"].float()))
+    if "grad_u_enc" in c:
+        check_tensor(pre + "grad_u_enc", u.grad, c["grad_u_enc"].float(), rel_l2(c["grad_u_enc_bf16"].float(), c["grad_u_enc"].float()))
+    if xl:
+        check_tensor(pre + "grad_global_projector", head.global_projector.projector.weight.grad, c["grad_global_projector"].float(),
+                     rel_l2(c["grad_global_projector_bf16"].float(), c["grad_global_projector"].float()))
 
 
-def test_sd_head_dummy_forward_and_config():
-    head, _, _ = _tiny_head()
-    head = head.to(DEV, BF)
+@pytest.mark.parametrize("use_graph", [True, False])
+@pytest.mark.parametrize("xl,name", [(xl, n) for xl in (False, True) for n in _PIPE_CASES[xl]])
+def test_sd_head_pipeline_vs_executed_reference(golden, xl, name, use_graph):
+    """`StableDiffusion(XL)Head.pipeline` (modeling_plugins.py:671-850, dreamllm_sdxl :239-445) against the executed reference:
+    deterministic DDIM for 1 / 10 / 50 steps (the hipGraph + fused CFG/DDIM loop and the plain loop), guidance_rescale,
+    no-CFG, the head's own ancestral DDPM scheduler with a generator, v-prediction with eta > 0, VAE decode (`pt`), latents
+    drawn from the generator, SDXL micro-conditioning."""
+    from dreamllm_amd.schedulers import DDIMScheduler, DDPMScheduler
+    from dreamllm_amd.utils import replay_draws
+    tag = "sdxl_head" if xl else "sd_head"
+    g = golden(tag + ".pt")
+    c = _case(g, "pipeline", name)
+    kw = dict(c["kwargs"])
+    fusable = c["scheduler"] == "DDIMScheduler" and kw["guidance_scale"] > 1 and kw["guidance_rescale"] == 0 and kw["eta"] == 0
+    if use_graph and not fusable:
+        pytest.skip("the hipGraph loop covers deterministic DDIM + CFG only; this case runs the plain loop")
+    head = _fixture_head(g, xl, prediction_type=c["prediction_type"])
+    sched = {"DDIMScheduler": DDIMScheduler, "DDPMScheduler": DDPMScheduler}[c["scheduler"]](prediction_type=c["prediction_type"])
+    cfg = kw["guidance_scale"] > 1.0
+    with replay_draws(c["draws"]):
+        out = head.pipeline(latents=None if c["latents"] is None else c["latents"].float().clone(),
+                            prompt_embeds=c["prompt_embeds"].to(BF).to(DEV),
+                            negative_prompt_embeds=c["negative_prompt_embeds"].to(BF).to(DEV) if cfg else None,
+                            generator=torch.Generator().manual_seed(c["gen_seed"]), scheduler=sched, use_graph=use_graph, **kw)
+    assert sched.timesteps.tolist() == c["timesteps"]
+    ref = c["out"].float()
+    check_tensor(f"{tag}.pipeline.{name}.{'graph' if use_graph else 'loop'}", out, ref, rel_l2(c["out_bf16"].float(), ref))
+
+
+def test_sd_head_dummy_forward_and_config(golden):
+    g = golden("sd_head.pt")
+    assert g["dummy"] == dict(loss=0.0, proj_grad_is_zero=True, dq_grad_is_zero=True)  # what the executed reference gives
+    head = _fixture_head(g, False)
     dq = torch.randn(1, 8, 128, device=DEV, dtype=BF, requires_grad=True)
     out = head(None, None, None, dq)
     out.backward()
     assert out.item() == 0.0 and head.projector.projector.weight.grad is not None
+    assert float(head.projector.projector.weight.grad.abs().sum()) == 0.0 and float(dq.grad.abs().sum()) == 0.0
     assert set(head.config) >= {"diffusion_name_or_path", "freeze_unet", "snr_gamma"}
     assert head.plugin_type == "head"
 
 
-def test_denoise_pipeline_ddim_vs_oracle_loop():
-    """StableDiffusionHead.pipeline (modeling_plugins.py:671-850) with the deterministic DDIM scheduler, CFG 7.5:
-    final latents after 1, 4 and 10 steps against the oracle loop over the oracle UNet."""
-    from dreamllm_amd.schedulers import DDIMScheduler
-    from oracle import unet_ref, sched_ref
-    head, ucfg, usd = _tiny_head()
-    pw = head.projector.projector.weight.data.clone()
-    B = 2
-    pe = bf16r(torch.randn(B, 8, 128) * 0.5)
-    ne = bf16r(torch.randn(B, 8, 128) * 0.5)
-    lat0 = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(42))
-    head = head.to(DEV, BF)
-    unet_fn = lambda x, t, c: unet_ref.unet_forward(bf16r(x), torch.tensor([t]), c, usd, ucfg)
-    for steps in (1, 4, 10):
-        ref = sched_ref.ddim_loop(unet_fn, lat0, F.linear(ne, pw), F.linear(pe, pw), steps, 7.5)
-        out = head.pipeline(num_inference_steps=steps, guidance_scale=7.5, latents=lat0.clone(), prompt_embeds=pe.to(DEV),
-                            negative_prompt_embeds=ne.to(DEV), output_type="latent", scheduler=DDIMScheduler())
-        e = rel_l2(out, ref)
-        assert e <= 1e-2 * steps**0.5 + 5e-3, (steps, e)
-
-
-# ----------------------------------------------------------------------------- SDXL head (SURVEY.md §8 a15)
-def _tiny_xl_head(embed=128, gdim=40):
-    from dreamllm_amd.modeling_plugins_sdxl import StableDiffusionXLHead
-    from oracle import unet_ref
-    ucfg = unet_ref.tiny_config(cross_dim=64, sdxl=True)
-    torch.manual_seed(5)
-    head = StableDiffusionXLHead(dict(unet=ucfg, vae=dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1)),
-                                 embed_hidden_size=embed, global_condition_hidden_size=gdim)
-    usd = {k: bf16r(v) for k, v in unet_ref.random_state_dict(ucfg, seed=2).items()}
-    head.unet.load_state_dict(usd)
-    for p in head.parameters():
-        p.data = bf16r(p.data)
-    return head, ucfg, usd
-
-
-def test_sdxl_head_training_loss_and_grad():
-    """StableDiffusionXLHead.forward (dreamllm_sdxl/modeling_plugins.py:151-236): mean-pooled global projector ->
-    `text_embeds`, `add_time_ids` -> SDXL UNet; loss and gradients of the dream states / both projectors vs the oracle."""
-    from oracle import unet_ref, vae_ref, sched_ref
-    head, ucfg, usd = _tiny_xl_head()
-    assert ucfg["projection_class_embeddings_input_dim"] == 40 + 6 * ucfg["addition_time_embed_dim"]
-    vsd = {k: v.clone() for k, v in head.vae.state_dict().items()}
-    pw = head.projector.projector.weight.data.clone()
-    gw = head.global_projector.projector.weight.data.clone()
-    N = 2
-    img = bf16r(torch.rand(N, 3, 128, 128) * 2 - 1)
-    enc = bf16r(torch.randn(N, 8, 128) * 0.5)
-    noise = bf16r(torch.randn(N, 4, 16, 16))
-    ts = torch.tensor([50, 800])
-    tids = torch.tensor([[128., 128, 0, 0, 128, 128], [200., 160, 8, 16, 128, 128]])
-    head = head.to(DEV, BF)
-    encd = enc.to(BF).to(DEV).requires_grad_(True)
-    torch.manual_seed(9)
-    loss = head(img.to(DEV), encd, None, tids.to(DEV), None, noise=noise.to(DEV), timesteps=ts.to(DEV))
-    loss.backward()
-    vcfg = dict(head.vae.config.to_dict())
-    mom = vae_ref.encode_moments(img, vsd, vcfg)
-    torch.manual_seed(9)
-    eps_v = torch.randn(mom[:, :4].shape, device=DEV).cpu()
-    lat = vae_ref.sample_latents(mom, eps_v, vcfg["scaling_factor"])
-    ac = sched_ref.alphas_cumprod()
-    noisy = torch.stack([sched_ref.add_noise(lat[i], noise[i], int(ts[i]), ac) for i in range(N)])
-    er = enc.clone().requires_grad_(True)
-    pwr, gwr = pw.clone().requires_grad_(True), gw.clone().requires_grad_(True)
-    added = dict(text_embeds=bf16r(F.linear(bf16r(er.mean(1)), gwr)), time_ids=tids)
-    pred = unet_ref.unet_forward(noisy, ts, F.linear(er, pwr), usd, ucfg, added_cond_kwargs=added)
-    lref = F.mse_loss(pred.float(), noise.float())
-    lref.backward()
-    assert abs(loss.item() - lref.item()) <= 2e-2 * abs(lref.item()), (loss.item(), lref.item())
-    assert rel_l2(encd.grad, er.grad) <= 6e-2
-    assert rel_l2(head.projector.projector.weight.grad, pwr.grad) <= 6e-2
-    assert rel_l2(head.global_projector.projector.weight.grad, gwr.grad) <= 8e-2
-
-
-def test_sdxl_head_dummy_forward_config_and_state_dict(tmp_path):
-    head, _, _ = _tiny_xl_head()
-    head = head.to(DEV, BF)
+def test_sdxl_head_dummy_forward_config_and_state_dict(golden, tmp_path):
+    g = golden("sdxl_head.pt")
+    # the reference's SDXL dummy branch cannot run: it feeds the PROJECTED dummy to the global projector (:165)
+    assert "cannot be multiplied" in g["dummy"]["error"]
+    head = _fixture_head(g, True)
     dq = torch.randn(1, 8, 128, device=DEV, dtype=BF, requires_grad=True)
     out = head(None, None, None, None, dq)
     out.backward()
@@ -393,34 +369,3 @@ def test_sdxl_head_dummy_forward_config_and_state_dict(tmp_path):
     head.load_model(str(tmp_path))
     assert torch.equal(head.global_projector.projector.weight.data, w)
     assert head.fsdp_ignored_modules() == [head.vae, head.unet]
-
-
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_sdxl_pipeline_ddim_vs_oracle_loop(use_graph):
-    """StableDiffusionXLHead.pipeline (dreamllm_sdxl/modeling_plugins.py:239-445), deterministic DDIM, CFG 7.5, both the
-    hipGraph + fused-update loop and the plain loop, against the oracle loop over the oracle SDXL UNet."""
-    from dreamllm_amd.schedulers import DDIMScheduler
-    from oracle import unet_ref, sched_ref
-    head, ucfg, usd = _tiny_xl_head()
-    pw = head.projector.projector.weight.data.clone()
-    gw = head.global_projector.projector.weight.data.clone()
-    B = 2
-    pe = bf16r(torch.randn(B, 8, 128) * 0.5)
-    ne = bf16r(torch.randn(B, 8, 128) * 0.5)
-    lat0 = torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(42))
-    head = head.to(DEV, BF)
-    full = ucfg["sample_size"] * 8
-    tids = torch.tensor([[float(full), full, 0, 0, full, full]] * (2 * B))
-    gl = torch.cat([bf16r(F.linear(bf16r(ne.mean(1)), gw)), bf16r(F.linear(bf16r(pe.mean(1)), gw))])
-
-    def unet_fn(x, t, c):  # the oracle loop calls it on the [uncond; cond] batch
-        return unet_ref.unet_forward(bf16r(x), torch.tensor([t]), c, usd, ucfg,
-                                     added_cond_kwargs=dict(text_embeds=gl, time_ids=tids))
-
-    for steps in (1, 4):
-        ref = sched_ref.ddim_loop(unet_fn, lat0, F.linear(ne, pw), F.linear(pe, pw), steps, 7.5)
-        out = head.pipeline(num_inference_steps=steps, guidance_scale=7.5, latents=lat0.clone(), prompt_embeds=pe.to(DEV),
-                            negative_prompt_embeds=ne.to(DEV), output_type="latent", scheduler=DDIMScheduler(),
-                            use_graph=use_graph)
-        e = rel_l2(out, ref)
-        assert e <= 1e-2 * steps**0.5 + 5e-3, (steps, e)
