@@ -162,8 +162,25 @@ class HipCLIPVisionModel(nn.Module):
         self._fused = None
         return self.load_state_dict(out, strict=True)
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        # any state-dict load that reaches this module (also through a parent plugin's load_state_dict / load_model)
+        # invalidates the fused QKV / padded patch weights
+        self._fused = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def _weights_key(self):
+        """(data_ptr, version) of every tensor the fused cache was built from: in-place updates (`copy_`, optimizer steps,
+        `load_state_dict`) bump the version, re-assignment / `.to()` change the pointer."""
+        vm = self.vision_model
+        ts = [vm.embeddings.patch_embedding.weight]
+        for l in vm.encoder.layers:
+            a = l.self_attn
+            ts += [a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.q_proj.bias, a.k_proj.bias, a.v_proj.bias]
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
     def _prepare(self):
-        if self._fused is not None and self._fused["dev"] == (self.device, self.dtype):
+        key = (self.device, self.dtype, self._weights_key())
+        if self._fused is not None and self._fused["dev"] == key:
             return self._fused
         vm = self.vision_model
         H = self.config.hidden_size
@@ -178,7 +195,7 @@ class HipCLIPVisionModel(nn.Module):
             layers.append(dict(
                 wqkv=torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).detach().contiguous(),
                 bqkv=torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).detach().contiguous()))
-        self._fused = dict(dev=(self.device, self.dtype), patch_w=wp, K=K, Kp=Kp, layers=layers)
+        self._fused = dict(dev=key, patch_w=wp, K=K, Kp=Kp, layers=layers)
         return self._fused
 
     @torch.no_grad()

@@ -55,17 +55,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
     const int b = blockIdx.z, h = blockIdx.y;
     const int qblk = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;
     const int hk = h / (P.H / P.Hkv);
-    const int sq_len = P.seqlens ? min(P.seqlens[b], P.Sq) : P.Sq;
-    const int sk_len = P.seqlens ? min(P.seqlens[b], P.Sk) : P.Sk;
+    const AttnSpan sp = attn_span(P, b);
+    const int sq_len = sp.sq_len, sk_len = sp.sk_len, SqE = sp.SqE;
     const int q0 = qblk * BQ, wq0 = q0 + wave * (QT * 16);
     const int coff = sk_len - sq_len;
     bf16* dqbase = P.dq + (int64_t)b * P.dq_sb + (int64_t)h * P.dq_sh;
     const int64_t dq_ss = P.dq_ss;
+    if (sp.qst > 0) {
+        if (qblk == 0) zero_head_rows<D, 256>(dqbase, dq_ss, sp.qst, tid);
+        dqbase += (int64_t)sp.qst * dq_ss;
+    }
 
     if (q0 >= sq_len) {
         for (int i = tid; i < BQ * (D / 8); i += 256) {
             const int r = q0 + i / (D / 8), c = i % (D / 8);
-            if (r < P.Sq) st_bf16x8(dqbase + (int64_t)r * dq_ss + c * 8, zero_bf16x8());
+            if (r < SqE) st_bf16x8(dqbase + (int64_t)r * dq_ss + c * 8, zero_bf16x8());
         }
         return;
     }
@@ -73,10 +77,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
     bf16x8 qf[QT][DS], dof[QT][DS];
     float lse2[QT], dlt[QT];
     {
-        const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh;
-        const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh;
-        const float* lsep = P.lse + ((int64_t)b * P.H + h) * P.Sq;
-        const float* dlp = P.delta + ((int64_t)b * P.H + h) * P.Sq;
+        const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
+        const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh + (int64_t)sp.qst * P.o_ss;
+        const float* lsep = P.lse + ((int64_t)b * P.H + h) * P.Sq + sp.qst;
+        const float* dlp = P.delta + ((int64_t)b * P.H + h) * P.Sq + sp.qst;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const int qrow = wq0 + qt * 16 + t;
@@ -104,8 +108,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
     int kv_end = sk_len;
     if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
     const int nblk = kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0;
-    const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh;
-    const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh;
+    const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+    const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
 
     f32x4 dqacc[DT][QT];
 #pragma unroll
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int qrow = wq0 + qt * 16 + t;
-        if (qrow < P.Sq) {
+        if (qrow < SqE) {
             const float sc = (qrow < sq_len) ? P.scale : 0.f;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -255,19 +259,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
     const int g = lane >> 4, t = lane & 15;
     const int b = blockIdx.z, hk = blockIdx.y;
     const int group = P.H / P.Hkv;
-    const int sq_len = P.seqlens ? min(P.seqlens[b], P.Sq) : P.Sq;
-    const int sk_len = P.seqlens ? min(P.seqlens[b], P.Sk) : P.Sk;
+    const AttnSpan sp = attn_span(P, b);
+    const int sq_len = sp.sq_len, sk_len = sp.sk_len, SkE = sp.SkE;
     const int k0 = blockIdx.x * BKEYS, wk0 = k0 + wave * (KT * 16);
     const int coff = sk_len - sq_len;
     bf16* dkbase = P.dk + (int64_t)b * P.dk_sb + (int64_t)hk * P.dk_sh;
     bf16* dvbase = P.dv + (int64_t)b * P.dk_sb + (int64_t)hk * P.dk_sh;
     const int64_t dk_ss = P.dk_ss;
+    if (sp.kst > 0) {
+        if (blockIdx.x == 0) {
+            zero_head_rows<D, 256>(dkbase, dk_ss, sp.kst, tid);
+            zero_head_rows<D, 256>(dvbase, dk_ss, sp.kst, tid);
+        }
+        dkbase += (int64_t)sp.kst * dk_ss;
+        dvbase += (int64_t)sp.kst * dk_ss;
+    }
 
     // this wave's keys as B operands: lane = key t of tile kt, d = ds*32 + g*8 ..
     bf16x8 kfB[KT][DS], vfB[KT][DS];
     {
-        const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh;
-        const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh;
+        const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+        const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             const int krow = wk0 + kt * 16 + t;
@@ -311,8 +323,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
     auto gload = [&](int it) {
         const int hq = hk * group + it / nq;
         const int qb = qb_begin + it % nq;
-        const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)hq * P.q_sh;
-        const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)hq * P.o_sh;
+        const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)hq * P.q_sh + (int64_t)sp.qst * P.q_ss;
+        const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)hq * P.o_sh + (int64_t)sp.qst * P.o_ss;
         if (qb * BQ + BQ <= sq_len) {  // whole tile inside the sequence: strength-reduced addressing
             sq.gload_full(qbase, P.q_ss, qb * BQ, goff_q);
             sdo.gload_full(dobase, P.o_ss, qb * BQ, goff_o);
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
         }
         if (tid < 128) {
             const int qi = qb * BQ + (tid & 63);
-            const float* src = (tid < 64 ? P.lse : P.delta) + ((int64_t)b * P.H + hq) * P.Sq;
+            const float* src = (tid < 64 ? P.lse : P.delta) + ((int64_t)b * P.H + hq) * P.Sq + sp.qst;
             stat = (qi < sq_len) ? src[qi] : 0.f;
         }
     };
@@ -440,7 +452,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) {
         const int krow = wk0 + kt * 16 + t;
-        if (krow < P.Sk) {
+        if (krow < SkE) {
             const bool ok = krow < sk_len;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
@@ -489,7 +501,8 @@ extern "C" {
 // [B,Sk,Hkv,D] views sharing strides dk_* (so gradients can be written straight into a packed dQKV buffer);
 // delta: fp32 [B,H,Sq] workspace.
 int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* o, const float* lse, float* delta,
-                  void* dq, void* dk, void* dv, const int* seqlens, int B, int H, int Hkv, int Sq, int Sk, int D, int64_t q_sb,
+                  void* dq, void* dk, void* dv, const int* seqlens, const int* seqstart, int B, int H, int Hkv, int Sq, int Sk, int D,
+                  int64_t q_sb,
                   int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
                   int64_t dq_sb, int64_t dq_ss, int64_t dq_sh, int64_t dk_sb, int64_t dk_ss, int64_t dk_sh, float scale,
                   int causal, void* stream) {
@@ -503,6 +516,7 @@ int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v,
     AttnParams P{};
     P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.o = (bf16*)o; P.dout = (const bf16*)dout;
     P.dq = (bf16*)dq; P.dk = (bf16*)dk; P.dv = (bf16*)dv; P.lse = (float*)lse; P.delta = delta; P.seqlens = seqlens;
+    P.seqstart = seqstart;
     P.B = B; P.H = H; P.Hkv = Hkv; P.Sq = Sq; P.Sk = Sk;
     P.q_sb = q_sb; P.q_ss = q_ss; P.q_sh = q_sh; P.k_sb = k_sb; P.k_ss = k_ss; P.k_sh = k_sh;
     P.o_sb = o_sb; P.o_ss = o_ss; P.o_sh = o_sh; P.scale = scale; P.causal = causal;

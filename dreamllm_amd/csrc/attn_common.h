@@ -130,7 +130,10 @@ struct AttnParams {
     const bf16* dout; bf16* dq; bf16* dk; bf16* dv;
     float* lse;          // [B, H, Sq]
     float* delta;        // [B, H, Sq]  rowsum(dO * O)
-    const int* seqlens;  // [B] valid length (self-attention with right padding) or null
+    const int* seqlens;  // [B] number of valid tokens of a padded self-attention batch (Sq == Sk), or null
+    const int* seqstart; // [B] index of the first valid key, or null (0): keys [start, start + len) are attended.  With
+                         // Sq == Sk the queries share the span (left / right padding, modeling_dreamllm.py:523-583); with
+                         // Sq != Sk (KV cache) every query is valid and sits at the END of the key axis.
     int B, H, Hkv, Sq, Sk;
     int64_t q_sb, q_ss, q_sh;      // element strides of q / o / dout / dq
     int64_t k_sb, k_ss, k_sh;      // element strides of k / v / dk / dv
@@ -140,6 +143,28 @@ struct AttnParams {
     float scale;
     int causal;
 };
+
+// Per-batch valid span after shifting every base pointer to the first valid token: all kernels index rows relative to it.
+struct AttnSpan {
+    int kst, qst;        // first valid key / query row (pointer shift)
+    int SqE, SkE;        // rows left on each axis after the shift (bounds of what may be written)
+    int sq_len, sk_len;  // valid queries / keys
+};
+__device__ __forceinline__ AttnSpan attn_span(const AttnParams& P, int b) {
+    AttnSpan s;
+    s.kst = P.seqstart ? max(0, min(P.seqstart[b], P.Sk)) : 0;
+    s.qst = (P.Sq == P.Sk) ? s.kst : 0;
+    s.SqE = P.Sq - s.qst;
+    s.SkE = P.Sk - s.kst;
+    s.sk_len = P.seqlens ? max(0, min(P.seqlens[b], s.SkE)) : s.SkE;
+    s.sq_len = (P.Sq == P.Sk) ? s.sk_len : s.SqE;
+    return s;
+}
+// rows [0, n) of a [rows][D] bf16 view := 0 (the pad rows in front of a left-padded sequence)
+template <int D, int NT>
+__device__ __forceinline__ void zero_head_rows(bf16* base, int64_t row_stride, int n, int tid) {
+    for (int i = tid; i < n * (D / 8); i += NT) st_bf16x8(base + (int64_t)(i / (D / 8)) * row_stride + (i % (D / 8)) * 8, zero_bf16x8());
+}
 
 // Pins a value loaded from global memory BEFORE a loop as "arrived": the empty asm consumes the register, so hipcc places the
 // s_waitcnt vmcnt for it here, once.  Without this the loop header merges "still pending" (the path around the guarded

@@ -29,30 +29,39 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     const int b = blockIdx.z, h = blockIdx.y;
     const int qblk = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;  // heavy causal blocks first
     const int hk = h / (P.H / P.Hkv);
-    const int sq_len = P.seqlens ? min(P.seqlens[b], P.Sq) : P.Sq;
-    const int sk_len = P.seqlens ? min(P.seqlens[b], P.Sk) : P.Sk;
+    const AttnSpan sp = attn_span(P, b);
+    const int sq_len = sp.sq_len, sk_len = sp.sk_len, SqE = sp.SqE;
     const int q0 = qblk * BQ, wq0 = q0 + wave * (QT * 16);
     const int coff = sk_len - sq_len;
 
     bf16* obase = P.o + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh;
     float* lsebase = P.lse ? P.lse + ((int64_t)b * P.H + h) * P.Sq : nullptr;
+    if (sp.qst > 0) {  // left padding: rows in front of the sequence are zeros too; then work relative to the first valid row
+        if (qblk == 0) {
+            zero_head_rows<D, 256>(obase, P.o_ss, sp.qst, tid);
+            if (lsebase)
+                for (int i = tid; i < sp.qst; i += 256) lsebase[i] = 0.f;
+        }
+        obase += (int64_t)sp.qst * P.o_ss;
+        if (lsebase) lsebase += sp.qst;
+    }
 
     if (q0 >= sq_len) {
         // padded tail of this sequence: zeros (pad_input semantics, modeling_dreamllm.py:545)
         for (int i = tid; i < BQ * (D / 8); i += 256) {
             const int r = q0 + i / (D / 8), c = i % (D / 8);
-            if (r < P.Sq) st_bf16x8(obase + (int64_t)r * P.o_ss + c * 8, zero_bf16x8());
+            if (r < SqE) st_bf16x8(obase + (int64_t)r * P.o_ss + c * 8, zero_bf16x8());
         }
         if (lsebase)
             for (int i = tid; i < BQ; i += 256)
-                if (q0 + i < P.Sq) lsebase[q0 + i] = 0.f;
+                if (q0 + i < SqE) lsebase[q0 + i] = 0.f;
         return;
     }
 
     // Q fragments (B operand of S^T = K Q^T): lane = query t of tile qt, d = ds*32 + g*8 ..
     bf16x8 qf[QT][DS];
     {
-        const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh;
+        const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const int qrow = wq0 + qt * 16 + t;
@@ -70,8 +79,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
     const int nblk = kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0;
 
-    const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh;
-    const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh;
+    const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+    const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
 
     f32x4 oacc[DT][QT];
 #pragma unroll
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
         const int qrow = wq0 + qt * 16 + t;
         const bool valid = qrow < sq_len;
         const float inv = (l > 0.f && valid) ? 1.0f / l : 0.f;
-        if (qrow < P.Sq) {
+        if (qrow < SqE) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 bf16x4 o;
@@ -228,9 +237,12 @@ int launch_fwd(const AttnParams& P, hipStream_t stream) {
 extern "C" {
 
 // q,o: [B,Sq,H,D] views (element strides sb, ss, sh; d contiguous); k,v: [B,Sk,Hkv,D] views sharing one stride set.
-// seqlens: optional int32[B] valid lengths for right-padded self-attention (Sq == Sk): keys >= len are masked and
-// query rows >= len are written as zeros.  lse: optional fp32 [B,H,Sq].
-int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B, int H, int Hkv,
+// seqlens: optional int32[B] valid lengths of a padded self-attention batch (Sq == Sk); seqstart: optional int32[B] index of
+// the first valid token (left padding; 0 when null).  Keys outside [start, start + len) are masked and query rows outside it
+// are written as zeros (pad_input semantics).  With Sq != Sk (KV cache) seqstart masks the first keys only and every query
+// is valid.  lse: optional fp32 [B,H,Sq].
+int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, const int* seqstart, int B,
+                  int H, int Hkv,
                   int Sq, int Sk, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
                   int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale, int causal, void* stream) {
     if (B < 0 || H <= 0 || Hkv <= 0 || Sq < 0 || Sk < 0 || (H % Hkv) != 0) return DLLM_ERR_SHAPE;
@@ -240,6 +252,7 @@ int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     if (seqlens != nullptr && Sq != Sk) return DLLM_ERR_SHAPE;
     AttnParams P{};
     P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.o = (bf16*)o; P.lse = lse; P.seqlens = seqlens;
+    P.seqstart = seqstart;
     P.B = B; P.H = H; P.Hkv = Hkv; P.Sq = Sq; P.Sk = Sk;
     P.q_sb = q_sb; P.q_ss = q_ss; P.q_sh = q_sh; P.k_sb = k_sb; P.k_ss = k_ss; P.k_sh = k_sh;
     P.o_sb = o_sb; P.o_ss = o_ss; P.o_sh = o_sh; P.scale = scale; P.causal = causal;

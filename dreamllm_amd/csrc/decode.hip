@@ -195,14 +195,17 @@ int launch_gemv_fused(const GemvFusedParams& P, int swiglu, hipStream_t s) {
 }
 
 // RoPE on the new token's q and k (modeling_dreamllm.py:184-209) + append of k, v to the KV cache, one launch.
-// q [B][H][D] in place; k [B][Hkv][D] rotated into kcache[b][pos[b]]; v copied into vcache[b][pos[b]].  pos on device.
+// q [B][H][D] in place; k [B][Hkv][D] rotated into kcache[b][slot]; v copied into vcache[b][slot]; slot = kv_len[b] - 1 when
+// kv_len is given (left-padded prompts: the rotary position is the row's own token count, the cache slot is not), else
+// pos[b].  pos / kv_len on device.
 __global__ __launch_bounds__(64) void rope_append_kernel(bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                          bf16* __restrict__ kc, bf16* __restrict__ vc, const float* __restrict__ cs,
-                                                         const float* __restrict__ sn, const int64_t* __restrict__ pos, int H,
-                                                         int Hkv, int D, int64_t q_sb, int64_t kv_sb, int64_t c_sb, int64_t c_ss,
+                                                         const float* __restrict__ sn, const int64_t* __restrict__ pos,
+                                                         const int* __restrict__ kv_len, int H, int Hkv, int D, int64_t q_sb, int64_t kv_sb, int64_t c_sb, int64_t c_ss,
                                                          int64_t c_sh) {
     const int b = blockIdx.y, hh = blockIdx.x, half = D >> 1;
     const int64_t p = pos[b];
+    const int64_t slot = kv_len ? (int64_t)kv_len[b] - 1 : p;
     const int i = threadIdx.x;  // pair index
     if (i >= half) return;
     const float c = cs[p * half + i], s = sn[p * half + i];
@@ -214,14 +217,14 @@ __global__ __launch_bounds__(64) void rope_append_kernel(bf16* __restrict__ q, c
     } else if (hh < H + Hkv) {
         const int hk = hh - H;
         const bf16* x = k + (int64_t)b * kv_sb + (int64_t)hk * D;
-        bf16* dst = kc + (int64_t)b * c_sb + p * c_ss + (int64_t)hk * c_sh;
+        bf16* dst = kc + (int64_t)b * c_sb + slot * c_ss + (int64_t)hk * c_sh;
         const float x1 = (float)x[i], x2 = (float)x[i + half];
         dst[i] = (bf16)(x1 * c - x2 * s);
         dst[i + half] = (bf16)(x2 * c + x1 * s);
     } else {
         const int hk = hh - H - Hkv;
         const bf16* x = v + (int64_t)b * kv_sb + (int64_t)hk * D;
-        bf16* dst = vc + (int64_t)b * c_sb + p * c_ss + (int64_t)hk * c_sh;
+        bf16* dst = vc + (int64_t)b * c_sb + slot * c_ss + (int64_t)hk * c_sh;
         dst[i] = x[i];
         dst[i + half] = x[i + half];
     }
@@ -245,7 +248,7 @@ __device__ __forceinline__ void merge(Partial& a, float bm, float bl, const floa
 template <int D>
 __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16* __restrict__ q, const bf16* __restrict__ kc,
                                                                   const bf16* __restrict__ vc, const int* __restrict__ kv_len,
-                                                                  float* __restrict__ ws, int H, int Hkv, int64_t q_sb, int64_t q_sh,
+                                                                  const int* __restrict__ kv_start, float* __restrict__ ws, int H, int Hkv, int64_t q_sb, int64_t q_sh,
                                                                   int64_t c_sb, int64_t c_ss, int64_t c_sh, float scale, int NS) {
     constexpr int LPK = D / 8;    // lanes per key
     constexpr int KPW = 64 / LPK;  // keys per wave per iteration
@@ -254,7 +257,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16* __
     const int hk = h / (H / Hkv);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPK, sub = lane % LPK;
-    const int len = kv_len[b];
+    const int start = kv_start ? kv_start[b] : 0;  // left-padded prompt: cache slots [0, start) hold pad tokens
+    const int len = max(0, kv_len[b] - start);
     const int per = (len + NS - 1) / NS;
     const int k_begin = split * per, k_end = min(len, k_begin + per);
 
@@ -269,8 +273,8 @@ __global__ __launch_bounds__(256) void attn_decode_partial_kernel(const bf16* __
     st.l = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) st.o[e] = 0.f;
-    const bf16* kbase = kc + (int64_t)b * c_sb + (int64_t)hk * c_sh + sub * 8;
-    const bf16* vbase = vc + (int64_t)b * c_sb + (int64_t)hk * c_sh + sub * 8;
+    const bf16* kbase = kc + (int64_t)b * c_sb + (int64_t)hk * c_sh + (int64_t)start * c_ss + sub * 8;
+    const bf16* vbase = vc + (int64_t)b * c_sb + (int64_t)hk * c_sh + (int64_t)start * c_ss + sub * 8;
     for (int key = k_begin + wave * KPW + grp; key < k_end; key += 4 * KPW) {
         const bf16x8 kv = ld_bf16x8(kbase + (int64_t)key * c_ss);
         const bf16x8 vv = ld_bf16x8(vbase + (int64_t)key * c_ss);
@@ -402,14 +406,15 @@ int dllm_gemv_fused(const void* x, const void* norm_w, float eps, const void* W0
     }
 }
 
-// RoPE of the step's q (in place) and k, append of rotated k and v to the caches at position pos[b] (device int64 [B]).
+// RoPE of the step's q (in place) and k with rotary position pos[b] (device int64 [B]); append of rotated k and v to cache slot
+// kv_len[b] - 1 (device int32 [B]) or, when kv_len is NULL, slot pos[b].
 int dllm_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
-                     const int64_t* pos, int B, int H, int Hkv, int D, int64_t q_sb, int64_t kv_sb, int64_t c_sb, int64_t c_ss,
+                     const int64_t* pos, const int* kv_len, int B, int H, int Hkv, int D, int64_t q_sb, int64_t kv_sb, int64_t c_sb, int64_t c_ss,
                      int64_t c_sh, void* stream) {
     if (B < 0 || H <= 0 || Hkv <= 0 || (D != 64 && D != 128) || pos == nullptr) return DLLM_ERR_SHAPE;
     if (B == 0) return DLLM_OK;
     hipLaunchKernelGGL(rope_append_kernel, dim3((unsigned)(H + 2 * Hkv), (unsigned)B), dim3(64), 0, (hipStream_t)stream, (bf16*)q,
-                       (const bf16*)k, (const bf16*)v, (bf16*)kcache, (bf16*)vcache, cos_tab, sin_tab, pos, H, Hkv, D, q_sb, kv_sb,
+                       (const bf16*)k, (const bf16*)v, (bf16*)kcache, (bf16*)vcache, cos_tab, sin_tab, pos, kv_len, H, Hkv, D, q_sb, kv_sb,
                        c_sb, c_ss, c_sh);
     return dllm_check_launch();
 }
@@ -420,7 +425,7 @@ int64_t dllm_attn_decode_ws_floats(int B, int H, int D, int nsplit) { return (in
 // One query token per (b, h) against a KV cache [B][S_max][Hkv][D] (element strides c_sb, c_ss, c_sh; d contiguous) whose valid
 // length per batch element is read from DEVICE memory (kv_len[b], positions 0 .. kv_len[b]-1 attended).  q / out: [B][H][D]
 // views with strides (q_sb, q_sh) / (o_sb, o_sh).  Same math as the 1-token case of DreamLLMAttention (softmax(q K^T * scale) V).
-int dllm_attn_decode(const void* q, const void* kcache, const void* vcache, const int* kv_len, void* out, float* ws, int B, int H,
+int dllm_attn_decode(const void* q, const void* kcache, const void* vcache, const int* kv_len, const int* kv_start, void* out, float* ws, int B, int H,
                      int Hkv, int D, int64_t q_sb, int64_t q_sh, int64_t c_sb, int64_t c_ss, int64_t c_sh, int64_t o_sb,
                      int64_t o_sh, float scale, int nsplit, void* stream) {
     if (B < 0 || H <= 0 || Hkv <= 0 || (H % Hkv) != 0 || nsplit < 1 || nsplit > 64) return DLLM_ERR_SHAPE;
@@ -432,12 +437,12 @@ int dllm_attn_decode(const void* q, const void* kcache, const void* vcache, cons
     const dim3 grid((unsigned)(B * H), (unsigned)nsplit);
     if (D == 128) {
         hipLaunchKernelGGL((attn_decode_partial_kernel<128>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kcache,
-                           (const bf16*)vcache, kv_len, ws, H, Hkv, q_sb, q_sh, c_sb, c_ss, c_sh, scale, nsplit);
+                           (const bf16*)vcache, kv_len, kv_start, ws, H, Hkv, q_sb, q_sh, c_sb, c_ss, c_sh, scale, nsplit);
         hipLaunchKernelGGL((attn_decode_combine_kernel<128>), dim3((unsigned)(B * H)), dim3(128), 0, s, ws, (bf16*)out, H, o_sb,
                            o_sh, nsplit);
     } else {
         hipLaunchKernelGGL((attn_decode_partial_kernel<64>), grid, dim3(256), 0, s, (const bf16*)q, (const bf16*)kcache,
-                           (const bf16*)vcache, kv_len, ws, H, Hkv, q_sb, q_sh, c_sb, c_ss, c_sh, scale, nsplit);
+                           (const bf16*)vcache, kv_len, kv_start, ws, H, Hkv, q_sb, q_sh, c_sb, c_ss, c_sh, scale, nsplit);
         hipLaunchKernelGGL((attn_decode_combine_kernel<64>), dim3((unsigned)(B * H)), dim3(64), 0, s, ws, (bf16*)out, H, o_sb,
                            o_sh, nsplit);
     }

@@ -124,13 +124,21 @@ class ShardedGradAdamW:
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None, bucket_mb=512,
                  state_dtype=None, update_fn=None, sumsq_fn=None, process_group=None):
+        """`params`: an iterable of parameters, or torch-style param groups `[{"params": [...], "weight_decay": 0.0}, ...]`
+        (the reference trainer excludes biases and `ALL_LAYERNORM_LAYERS` weights from decay, omni/train/trainer.py:388-411):
+        a bucket never mixes decay values.  Invariant shared with DDP's `static_graph`: every trainable parameter receives
+        a gradient every step (the gradients live in flat buffers, so "no gradient" cannot be told from a zero gradient)."""
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
         self.rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.lr, self.betas, self.eps = lr, betas, eps
         self.max_grad_norm = max_grad_norm
         self._step = 0
         self.last_grad_norm = None
+        # the collectives are chosen ONCE, from the backend: RCCL has reduce_scatter_tensor / all_gather_into_tensor; the gloo
+        # transport of the CPU tests does not, and takes all_reduce + all_gather.  No fallback inside step(): a failing
+        # collective must surface, not silently switch pattern on one rank.
+        self.tensor_collectives = self.world > 1 and dist.get_backend(self.pg) == "nccl"
         if update_fn is None:
             from . import ops
 
@@ -142,21 +150,29 @@ class ShardedGradAdamW:
                 ops.sumsq_partials_(g, parts)
                 return ops.reduce_sum_f32(parts)
         self.update_fn, self.sumsq_fn = update_fn, sumsq_fn
-        params = [p for p in params if p.requires_grad]
-        if not params:
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            groups = [([p for p in g["params"] if p.requires_grad], float(g.get("weight_decay", weight_decay))) for g in params]
+        else:
+            groups = [([p for p in params if p.requires_grad], float(weight_decay))]
+        flat = [(p, wd) for ps, wd in groups for p in ps]
+        if not flat:
             raise ValueError("no trainable parameters")
         # buckets in REVERSE registration order: the last layers' gradients are complete first
         cap = bucket_mb * 1024 * 1024
-        self.buckets, cur, cur_bytes = [], [], 0
-        for p in reversed(params):
+        self.buckets, self.bucket_wd, cur, cur_bytes, cur_wd = [], [], [], 0, None
+        for p, wd in reversed(flat):
             nb = p.numel() * p.element_size()
-            if cur and (cur_bytes + nb > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
+            if cur and (cur_bytes + nb > cap or p.dtype != cur[0].dtype or p.device != cur[0].device or wd != cur_wd):
                 self.buckets.append(cur)
+                self.bucket_wd.append(cur_wd)
                 cur, cur_bytes = [], 0
             cur.append(p)
+            cur_wd = wd
             cur_bytes += nb
         if cur:
             self.buckets.append(cur)
+            self.bucket_wd.append(cur_wd)
         self.flat_p, self.flat_g, self.shard_m, self.shard_v, self.layout = [], [], [], [], []
         for bucket in self.buckets:
             n = sum(p.numel() for p in bucket)
@@ -187,6 +203,24 @@ class ShardedGradAdamW:
     def state_bytes_per_rank(self) -> int:
         return sum(m.numel() * m.element_size() + v.numel() * v.element_size() for m, v in zip(self.shard_m, self.shard_v))
 
+    def state_dict(self) -> dict:
+        """This rank's optimizer shard (the moments exist only for the local 1/N slice of every bucket) plus the step and the
+        bucket layout it belongs to.  Save one file per rank; `load_state_dict` refuses a shard of a different layout."""
+        return dict(step=self._step, world=self.world, rank=self.rank, layout=[tuple(l) for l in self.layout],
+                    weight_decay=list(self.bucket_wd), exp_avg=[m.clone() for m in self.shard_m],
+                    exp_avg_sq=[v.clone() for v in self.shard_v])
+
+    def load_state_dict(self, sd: dict):
+        if sd["world"] != self.world or sd["rank"] != self.rank or [tuple(l) for l in sd["layout"]] != [tuple(l) for l in self.layout]:
+            raise ValueError(f"optimizer shard of rank {sd['rank']}/{sd['world']} with layout {sd['layout']} does not match this "
+                             f"run (rank {self.rank}/{self.world}, layout {self.layout}): same world size, parameters and "
+                             "bucket_mb are required")
+        self._step = int(sd["step"])
+        for dst, src in zip(self.shard_m, sd["exp_avg"]):
+            dst.copy_(src)
+        for dst, src in zip(self.shard_v, sd["exp_avg_sq"]):
+            dst.copy_(src)
+
     @torch.no_grad()
     def step(self):
         self._step += 1
@@ -195,9 +229,9 @@ class ShardedGradAdamW:
         for fg, (n, padded, shard) in zip(self.flat_g, self.layout):
             if W > 1:
                 out = torch.empty(shard, dtype=fg.dtype, device=fg.device)
-                try:
+                if self.tensor_collectives:
                     dist.reduce_scatter_tensor(out, fg, op=dist.ReduceOp.SUM, group=self.pg)
-                except RuntimeError:  # transport without a reduce-scatter for this device type (gloo + CUDA tensors in tests)
+                else:
                     dist.all_reduce(fg, op=dist.ReduceOp.SUM, group=self.pg)
                     out.copy_(fg[r * shard:(r + 1) * shard])
                 out.div_(W)  # mean, as DDP (ReduceOp.AVG is not available on every backend)
@@ -213,13 +247,58 @@ class ShardedGradAdamW:
             self.last_grad_norm = norm
             coef = torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0).reshape(1).to(torch.float32)
         b1, b2 = self.betas
-        for fp, g, m, v, (n, padded, shard) in zip(self.flat_p, gshards, self.shard_m, self.shard_v, self.layout):
+        for fp, g, m, v, wd, (n, padded, shard) in zip(self.flat_p, gshards, self.shard_m, self.shard_v, self.bucket_wd, self.layout):
             pshard = fp[r * shard:(r + 1) * shard]
-            self.update_fn(pshard, g, m, v, self.lr, b1, b2, self.eps, self.weight_decay, self._step, coef)
+            self.update_fn(pshard, g, m, v, self.lr, b1, b2, self.eps, wd, self._step, coef)
             if W > 1:
-                try:
+                if self.tensor_collectives:
                     dist.all_gather_into_tensor(fp, pshard.clone(), group=self.pg)
-                except RuntimeError:
+                else:
                     parts = [torch.empty_like(pshard) for _ in range(W)]
                     dist.all_gather(parts, pshard.clone(), group=self.pg)
                     fp.copy_(torch.cat(parts))
+
+
+def decay_param_groups(model: torch.nn.Module, weight_decay: float):
+    """Param groups as the reference trainer builds them (omni/train/trainer.py:388-411, HF `get_parameter_names`): weights of
+    `ALL_LAYERNORM_LAYERS` modules (DreamLLMRMSNorm registers itself there, modeling_dreamllm.py:94) and biases get no decay."""
+    from transformers.pytorch_utils import ALL_LAYERNORM_LAYERS
+    norm_types = tuple(ALL_LAYERNORM_LAYERS)
+    no_decay = set()
+    for mn, mod in model.named_modules():
+        for pn, _ in mod.named_parameters(recurse=False):
+            full = f"{mn}.{pn}" if mn else pn
+            if isinstance(mod, norm_types) or pn.endswith("bias"):
+                no_decay.add(full)
+    dec = [p for n, p in model.named_parameters() if p.requires_grad and n not in no_decay]
+    nod = [p for n, p in model.named_parameters() if p.requires_grad and n in no_decay]
+    return [{"params": dec, "weight_decay": weight_decay}, {"params": nod, "weight_decay": 0.0}]
+
+
+def save_dreamllm_full_state_dict(model, output_dir: str, rank: int | None = None):
+    """Plugin-aware full-state-dict save: the counterpart of `save_dreamllm_fsdp_full_state_dict`
+    (omni/utils/fsdp_utils.py:23-61, called by omni/train/dreamllm_trainer.py:54) for the sharded-gradient mode.  Parameters are
+    whole on every rank here, so nothing has to be gathered: rank 0 writes `pytorch_model.bin` (the full state dict, plugin
+    keys included, exactly like the reference) and one `{plugin.save_model_name}.bin` per plugin with the
+    `model.{name}.` / `{name}.` prefix stripped -- the files `PluginBase.load_model` reads back."""
+    import os as _os
+    from collections import OrderedDict
+    rank = get_rank() if rank is None else rank
+    inner = model.module if hasattr(model, "module") else model
+    state_dict = inner.state_dict()
+    weights = {}
+    for plugin_name, ptype in inner.config.plugins_type.items():
+        if ptype == "embedding":
+            plugin, prefix = getattr(inner.get_decoder(), plugin_name), f"model.{plugin_name}."
+        elif ptype == "head":
+            plugin, prefix = getattr(inner, plugin_name), f"{plugin_name}."
+        else:
+            continue
+        weights[plugin.save_model_name] = OrderedDict((k[len(prefix):], v) for k, v in state_dict.items() if k.startswith(prefix))
+    if rank == 0:
+        _os.makedirs(output_dir, exist_ok=True)
+        torch.save(state_dict, _os.path.join(output_dir, "pytorch_model.bin"))
+        for name, sd in weights.items():
+            torch.save(sd, _os.path.join(output_dir, f"{name}.bin"))
+    synchronize()
+    return sorted(weights)

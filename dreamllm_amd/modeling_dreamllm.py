@@ -110,7 +110,7 @@ class _DecoderLayerFn(torch.autograd.Function):
     """DreamLLMDecoderLayer.forward (modeling_dreamllm.py:622-640) with a hand-written backward."""
 
     @staticmethod
-    def forward(ctx, x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, n_heads, n_kv, eps, want_kv):
+    def forward(ctx, x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, n_heads, n_kv, eps, want_kv):
         B, S, Hd = x.shape
         hd = Hd // n_heads
         h, _, rstd1 = ops.rmsnorm_fwd(x, w_in, eps)
@@ -121,7 +121,7 @@ class _DecoderLayerFn(torch.autograd.Function):
         ops.rope_(q, cos, sin, pos)
         ops.rope_(k, cos, sin, pos)
         need_bwd = any(ctx.needs_input_grad[:10])
-        o, lse = ops.attn_fwd(q, k, v, True, 1.0 / math.sqrt(hd), seqlens, need_lse=need_bwd)
+        o, lse = ops.attn_fwd(q, k, v, True, 1.0 / math.sqrt(hd), seqlens, need_lse=need_bwd, seqstart=seqstart)
         x2 = ops.linear_fwd(o.view(B, S, Hd), wo, residual=x)
         h2, _, rstd2 = ops.rmsnorm_fwd(x2, w_post, eps)
         g = ops.linear_fwd(h2, wg)
@@ -130,8 +130,8 @@ class _DecoderLayerFn(torch.autograd.Function):
         act = ops.glu_fwd(g, u, 0)
         y = ops.linear_fwd(act, wd, residual=x2)
         if need_bwd:
-            ctx.save_for_backward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, rstd1, q, k, v, o, lse,
-                                  x2, rstd2, g, u)
+            ctx.save_for_backward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, q, k, v, o,
+                                  lse, x2, rstd2, g, u)
             ctx.cfg = (n_heads, n_kv, eps)
         if want_kv:
             ctx.mark_non_differentiable(k, v)
@@ -140,7 +140,7 @@ class _DecoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dk, _dv):
-        (x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, rstd1, q, k, v, o, lse, x2, rstd2, g,
+        (x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, q, k, v, o, lse, x2, rstd2, g,
          u) = ctx.saved_tensors
         n_heads, n_kv, eps = ctx.cfg
         B, S, Hd = x.shape
@@ -173,7 +173,7 @@ class _DecoderLayerFn(torch.autograd.Function):
         # ---- attention
         do = ops.linear_dgrad(dx2, wo).view(B, S, n_heads, hd)
         dwo = ops.linear_wgrad(dx2, o.view(B, S, Hd)) if need[5] else None
-        dq, dk, dv = ops.attn_bwd(do, q, k, v, o, lse, True, 1.0 / math.sqrt(hd), seqlens)
+        dq, dk, dv = ops.attn_bwd(do, q, k, v, o, lse, True, 1.0 / math.sqrt(hd), seqlens, seqstart=seqstart)
         del do
         ops.rope_(dq, cos, sin, pos, backward=True)
         ops.rope_(dk, cos, sin, pos, backward=True)
@@ -192,7 +192,7 @@ class _DecoderLayerFn(torch.autograd.Function):
         ops.gemm(dk2, wk, T, Hd, wk.shape[0], dk2.stride(0), Hd, 0, 1, out=dh, accumulate=True)
         ops.gemm(dv2, wv, T, Hd, wv.shape[0], dv2.stride(0), Hd, 0, 1, out=dh, accumulate=True)
         dx, dw_in = ops.rmsnorm_bwd(dh, x, w_in, rstd1, dh_in=dx2, need_dw=need[1])
-        return (dx.view(x.shape), dw_in, dwq, dwk, dwv, dwo, dw_post, dwg, dwu, dwd) + (None,) * 8
+        return (dx.view(x.shape), dw_in, dwq, dwk, dwv, dwo, dw_post, dwg, dwu, dwd) + (None,) * 9
 
 
 class DreamLLMMLP(nn.Module):
@@ -272,8 +272,10 @@ class DreamLLMAttention(nn.Module):
             k = torch.cat([past_key_value[0].transpose(1, 2), k], dim=1)
             v = torch.cat([past_key_value[1].transpose(1, 2), v], dim=1)
         present = (k.transpose(1, 2), v.transpose(1, 2)) if use_cache else None
-        seqlens = _mask_to_seqlens(attention_mask) if past == 0 else None
-        o = ops.flash_attn(q, k, v, causal=True, seqlens=seqlens)
+        seqstart, seqlens = kwargs.get("seqstart"), kwargs.get("seqlens")
+        if seqstart is None and seqlens is None:
+            seqstart, seqlens = _mask_to_spans(attention_mask, q_len=S)
+        o = ops.flash_attn(q, k, v, causal=True, seqlens=seqlens, seqstart=seqstart)
         out = ops.linear(o.reshape(B, S, self.hidden_size), self.o_proj.weight)
         return out, None, present
 
@@ -281,14 +283,46 @@ class DreamLLMAttention(nn.Module):
 DreamLLMFlashAttention2 = DreamLLMAttention  # same module: flash semantics are the only execution path
 
 
-def _mask_to_seqlens(attention_mask):
-    """2-D [B,S] mask with RIGHT padding (collator pads right: builder_dreamllm.py:466-482, tokenizer padding_side
-    'right' train.py:74) -> int32 lengths, computed on device (no host sync).  A 4-D additive mask is rejected."""
+def _mask_to_spans(attention_mask, q_len=None):
+    """2-D padding mask [B, Sk] -> (seqstart, seqlens): int32 [B] device tensors (or None) describing the ONE contiguous run
+    of valid tokens of every row, which is what the flash kernels take instead of the reference's unpad / pad round trip
+    (`_get_unpad_data` / `_upad_input`, modeling_dreamllm.py:69-74,553-583).
+
+    * right padding (collator, builder_dreamllm.py:466-482; tokenizer padding_side "right", train.py:74): start 0;
+    * left padding (inference callers: omni/eval/vqa/vqa_inference.py:276, omni/eval/text2img/ddp_sample_coco.py:64,
+      projects/dreamllm/cli_stable_diffusion_pipeline.py:19): start = number of pad tokens in front;
+    * `q_len < Sk` (a KV cache is attached): the run has to reach the last key -- the new tokens are valid by
+      construction -- and only `seqstart` is returned.
+    A mask with holes or more than one run cannot be expressed and raises ValueError (the reference's eager path would
+    honour it; silently attending to pad tokens is never an option).  A 4-D additive mask is rejected.  The check reads
+    one flag back from the device (skipped under stream capture); callers that already know the spans pass
+    `seqlens=` / `seqstart=` instead of a mask and stay sync-free (bench.py, data.collate_interleaved)."""
     if attention_mask is None:
-        return None
+        return None, None
     if attention_mask.dim() != 2:
         raise ValueError("the HIP decoder takes a 2-D padding mask (flash-attention path); 4-D additive masks are not supported")
-    return attention_mask.sum(dim=-1, dtype=torch.int32).contiguous()
+    m = attention_mask != 0
+    B, Sk = m.shape
+    lens = m.sum(dim=-1, dtype=torch.int32)
+    start = torch.argmax(m.to(torch.int8), dim=-1).to(torch.int32)  # first valid position (0 for an all-pad row)
+    with_cache = q_len is not None and q_len != Sk
+    if not (m.is_cuda and torch.cuda.is_current_stream_capturing()):
+        ar = torch.arange(Sk, device=m.device, dtype=torch.int32)[None]
+        run = (ar >= start[:, None]) & (ar < (start + lens)[:, None])
+        flags = torch.stack([(run == m).all(), (start == 0).all(), (lens == Sk).all(),
+                             ((start + lens == Sk) | (lens == 0)).all()]).tolist()
+        if not flags[0]:
+            raise ValueError("attention_mask must mark ONE contiguous run of valid tokens per row (left or right padding); "
+                             "masks with holes are not supported by the flash-attention path")
+        if with_cache and not flags[3]:
+            raise ValueError("with past_key_values the valid keys must extend to the newest token (left padding only)")
+        if flags[1] and flags[2]:
+            return None, None  # dense batch
+        if flags[1]:
+            start = None
+    if with_cache:
+        return (start.contiguous() if start is not None else None), None
+    return (start.contiguous() if start is not None else None), lens.contiguous()
 
 
 class DreamLLMDecoderLayer(nn.Module):
@@ -310,16 +344,16 @@ class DreamLLMDecoderLayer(nn.Module):
         if past_key_value is None:
             B, S, _ = hidden_states.shape
             cos, sin = a.rotary_emb.tables(S, hidden_states.device)
-            seqlens = kwargs.get("seqlens", None)
-            if seqlens is None:
-                seqlens = _mask_to_seqlens(attention_mask)
+            seqlens, seqstart = kwargs.get("seqlens", None), kwargs.get("seqstart", None)
+            if seqlens is None and seqstart is None:
+                seqstart, seqlens = _mask_to_spans(attention_mask)
             pos = None
             if position_ids is not None:
                 pos = position_ids.expand(B, S).contiguous().view(-1).long()
             y, k, v = _DecoderLayerFn.apply(
                 hidden_states.contiguous(), self.input_layernorm.weight, a.q_proj.weight, a.k_proj.weight, a.v_proj.weight,
                 a.o_proj.weight, self.post_attention_layernorm.weight, self.mlp.gate_proj.weight, self.mlp.up_proj.weight,
-                self.mlp.down_proj.weight, cos, sin, pos, seqlens, a.num_heads, a.num_key_value_heads,
+                self.mlp.down_proj.weight, cos, sin, pos, seqlens, seqstart, a.num_heads, a.num_key_value_heads,
                 self.input_layernorm.variance_epsilon, bool(use_cache))
             outputs = (y,)
             if use_cache:
@@ -329,7 +363,7 @@ class DreamLLMDecoderLayer(nn.Module):
         residual = hidden_states
         h = self.input_layernorm(hidden_states)
         h, _, present = a(h, attention_mask=attention_mask, position_ids=position_ids, past_key_value=past_key_value,
-                          use_cache=use_cache)
+                          use_cache=use_cache, seqstart=kwargs.get("seqstart"), seqlens=kwargs.get("seqlens"))
         hidden_states = ops.add(residual, h)
         residual = hidden_states
         h = self.mlp(self.post_attention_layernorm(hidden_states))
@@ -457,8 +491,10 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
         return ops.embedding(self.embed_tokens.weight, input_ids)
 
     def _forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
-                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, seqlens=None):
-        """modeling_dreamllm.py:846-1043."""
+                 use_cache=None, output_attentions=None, output_hidden_states=None, return_dict=None, seqlens=None,
+                 seqstart=None):
+        """modeling_dreamllm.py:846-1043.  `seqlens` / `seqstart` (int32 [B], device) describe the valid span of every row
+        directly and replace the mask (sync-free); otherwise the spans are derived from `attention_mask` once per forward."""
         output_hidden_states = output_hidden_states if output_hidden_states is not None else self.config.output_hidden_states
         use_cache = use_cache if use_cache is not None else self.config.use_cache
         return_dict = return_dict if return_dict is not None else getattr(self.config, "return_dict", True)
@@ -475,8 +511,12 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
             inputs_embeds = self.embed(input_ids)
         if position_ids is None and past_len > 0:
             position_ids = torch.arange(past_len, seq_length + past_len, dtype=torch.long, device=inputs_embeds.device)[None]
-        if seqlens is None and attention_mask is not None and past_len == 0:
-            seqlens = _mask_to_seqlens(attention_mask)  # device-side; the all-ones case costs nothing extra in the kernel
+        if seqlens is None and seqstart is None and attention_mask is not None:
+            if attention_mask.shape[-1] != seq_length + past_len:
+                raise ValueError(f"attention_mask covers {attention_mask.shape[-1]} positions, expected past + new = "
+                                 f"{past_len} + {seq_length} (modeling_dreamllm.py:960-967)")
+            seqstart, seqlens = _mask_to_spans(attention_mask, q_len=seq_length)  # once per forward, not per layer
+            attention_mask = None
         if self.training and use_cache:
             use_cache = False
         hidden_states = inputs_embeds
@@ -488,7 +528,8 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
                 all_hidden_states += (hidden_states,)
             past_key_value = past_key_values[idx] if past_key_values is not None else None
             layer_outputs = decoder_layer(hidden_states, attention_mask=attention_mask, position_ids=position_ids,
-                                          past_key_value=past_key_value, use_cache=use_cache, seqlens=seqlens)
+                                          past_key_value=past_key_value, use_cache=use_cache, seqlens=seqlens,
+                                          seqstart=seqstart)
             hidden_states = layer_outputs[0]
             if use_cache:
                 next_decoder_cache += (layer_outputs[1],)
@@ -504,7 +545,7 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
 
     def forward(self, input_ids=None, images=None, images_dm=None, attention_mask=None, position_ids=None,
                 past_key_values=None, inputs_embeds=None, use_cache=None, output_attentions=None, output_hidden_states=None,
-                return_dict=None, dream_index=None, image_index=None, seqlens=None):
+                return_dict=None, dream_index=None, image_index=None, seqlens=None, seqstart=None):
         """modeling_dreamllm.py:1045-1158.  `dream_index` / `image_index` (flat row indices from the data pipeline) are an
         optional fast path that skips the device->host sync of locating the slots; semantics are unchanged."""
         embed_tokens_backup = getattr(self, "embed_tokens_backup", None)
@@ -550,7 +591,7 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
         return self._forward(input_ids=None, attention_mask=attention_mask, position_ids=position_ids,
                              past_key_values=past_key_values, inputs_embeds=inputs_embeds, use_cache=use_cache,
                              output_attentions=output_attentions, output_hidden_states=output_hidden_states,
-                             return_dict=return_dict, seqlens=seqlens)
+                             return_dict=return_dict, seqlens=seqlens, seqstart=seqstart)
 
     def prepare_dream_queries_with_special_token(self, batch_size: int = 1):
         """modeling_dreamllm.py:1161-1169."""
@@ -624,7 +665,7 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
 
     def forward(self, input_ids=None, images=None, images_dm=None, attention_mask=None, position_ids=None,
                 past_key_values=None, inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
-                output_hidden_states=None, return_dict=None, dream_index=None, image_index=None, seqlens=None):
+                output_hidden_states=None, return_dict=None, dream_index=None, image_index=None, seqlens=None, seqstart=None):
         """modeling_dreamllm.py:1353-1509."""
         if input_ids is not None:
             assert (
@@ -639,7 +680,7 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
                              position_ids=position_ids, past_key_values=past_key_values, inputs_embeds=inputs_embeds,
                              use_cache=use_cache, output_attentions=output_attentions,
                              output_hidden_states=output_hidden_states, return_dict=True, dream_index=dream_index,
-                             image_index=image_index, seqlens=seqlens)
+                             image_index=image_index, seqlens=seqlens, seqstart=seqstart)
         hidden_states = outputs.last_hidden_state
         B, S, H = hidden_states.shape
 
@@ -726,51 +767,112 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
         return model_inputs
 
     @torch.no_grad()
-    def greedy_generate(self, input_ids, max_new_tokens, images=None, fast=None, use_graph=True):
-        """Greedy decode with a KV cache: the loop of omni/eval/language_eval/modeling_dreamllm.py:76-97 with
-        temperature == 0 (argmax, :92).  `fast` (default: batch <= 8) runs the token steps on the decode kernels
-        (GEMV + cache attention, one hipGraph replay per token: `decode.GreedyDecodeSession`); `fast=False` re-enters the model
-        forward per token like the reference loop does."""
+    def greedy_generate(self, input_ids, max_new_tokens, images=None, fast=None, use_graph=True, attention_mask=None,
+                        pad_token_id=None, vocab_limit="auto"):
+        """Greedy decode with a KV cache: the loop of omni/eval/language_eval/modeling_dreamllm.py:47-109 with
+        temperature == 0 (argmax over `logits[..., :32000]`, :79,86,92 -- `vocab_limit`).
+
+        * `pad_token_id` given: the reference loop's ragged-batch protocol -- `input_ids` is RIGHT-padded with
+          `pad_token_id`, the prefill covers the shortest prompt, and rows still inside their prompt are teacher-forced
+          (`input_text_mask`, :72,93-94).  Returns the `tokens` buffer [B, max_prompt + max_new_tokens].
+        * `attention_mask` given (LEFT-padded, HF-generate callers such as omni/eval/vqa/vqa_inference.py:276): mask-aware
+          position ids (`prepare_inputs_for_generation`), pad keys masked.  Returns cat([input_ids, new tokens]).
+        * neither: a dense batch.
+        `vocab_limit="auto"`: 32000 for the language-eval protocols (the loop's own slice), the whole vocabulary when an
+        `attention_mask` selects HF-generate semantics (HF's greedy search does not slice).
+        `fast` (default: batch <= 8) runs the token steps on the decode kernels (GEMV + cache attention, one hipGraph replay
+        per token: `decode.GreedyDecodeSession`); `fast=False` re-enters the model forward per token like the reference."""
         B, S = input_ids.shape
+        dev = input_ids.device
+        if vocab_limit == "auto":
+            vocab_limit = None if attention_mask is not None else 32000
+        V = min(int(vocab_limit), self.config.vocab_size) if vocab_limit is not None else self.config.vocab_size
         if fast is None:
             fast = B <= 8
+        tokens = forced = fmask = None
+        if pad_token_id is not None:
+            if attention_mask is not None:
+                raise ValueError("pass either pad_token_id (right-padded ragged prompts) or attention_mask (left-padded), not both")
+            text_mask = input_ids != pad_token_id
+            plen = text_mask.sum(-1)
+            if not bool((text_mask == (torch.arange(S, device=dev)[None] < plen[:, None])).all()):
+                raise ValueError("pad_token_id protocol: prompts must be right-padded")
+            s0 = int(plen.min())
+            total = S + max_new_tokens
+            tokens = torch.full((B, total), pad_token_id, dtype=torch.long, device=dev)
+            tokens[:, :S] = input_ids
+            fmask = torch.zeros(B, total, dtype=torch.bool, device=dev)
+            fmask[:, :S] = text_mask
+            forced, fm = tokens[:, s0:], fmask[:, s0:]
+            n_new = total - s0
+            prompt = input_ids[:, :s0]
+        else:
+            prompt, n_new, fm = input_ids, max_new_tokens, None
         if fast:
             from .decode import GreedyDecodeSession
-            key = (B, S + max_new_tokens + 1, use_graph)
+            key = (B, prompt.shape[1] + n_new + 1, use_graph, V)
             sess = getattr(self, "_decode_session", None)
             if sess is None or sess[0] != key:
-                sess = (key, GreedyDecodeSession(self, B, key[1], use_graph=use_graph))
+                sess = (key, GreedyDecodeSession(self, B, key[1], use_graph=use_graph, vocab_limit=V))
                 self._decode_session = sess
             sess = sess[1]
-            first = sess.prefill(input_ids, images=images)
-            rest = sess.generate(max_new_tokens - 1)
-            return torch.cat([input_ids, first[:, None], rest], dim=1)
-        out = self(input_ids=input_ids, images=images, use_cache=True, return_dict=True)
-        past = out.past_key_values
-        tokens = [out.logits[:, -1].argmax(-1)]
-        for _ in range(max_new_tokens - 1):
-            out = self(input_ids=tokens[-1][:, None], past_key_values=past, use_cache=True, return_dict=True)
-            past = out.past_key_values
-            tokens.append(out.logits[:, -1].argmax(-1))
-        return torch.cat([input_ids, torch.stack(tokens, 1)], dim=1)
+            first = sess.prefill(prompt, images=images, attention_mask=attention_mask, forced_tokens=forced, forced_mask=fm)
+            rest = sess.generate(n_new - 1)
+            new = torch.cat([first[:, None], rest], dim=1)
+        else:
+            position_ids = None
+            if attention_mask is not None:
+                position_ids = (attention_mask.long().cumsum(-1) - 1).masked_fill(attention_mask == 0, 1)
+            out = self(input_ids=prompt, images=images, attention_mask=attention_mask, position_ids=position_ids, use_cache=True,
+                       return_dict=True)
+            past, mask, new = out.past_key_values, attention_mask, []
+            for i in range(n_new):
+                nxt = out.logits[:, -1, :V].argmax(-1)
+                if fm is not None:
+                    nxt = torch.where(fm[:, i], forced[:, i], nxt)
+                new.append(nxt)
+                if i + 1 == n_new:
+                    break
+                pos = None
+                if mask is not None:
+                    mask = torch.cat([mask, mask.new_ones(B, 1)], dim=1)
+                    pos = (mask.long().sum(-1) - 1)[:, None]
+                out = self(input_ids=nxt[:, None], past_key_values=past, attention_mask=mask, position_ids=pos, use_cache=True,
+                           return_dict=True)
+                past = out.past_key_values
+            new = torch.stack(new, 1)
+        if tokens is not None:
+            tokens[:, s0:] = new
+            return tokens
+        return torch.cat([input_ids, new], dim=1)
 
     @torch.no_grad()
     def get_prompt_embeds(self, input_ids, attention_mask=None, images=None):
         """Prompt -> dream-query hidden states (modeling_dreamllm.py:1598-1672): prefill the text with a KV cache, then run
-        [<dream_start>, 64 queries, <dream_end>] against it and take the query positions of the last hidden state."""
+        [<dream_start>, 64 queries, <dream_end>] against it with the mask `cat([text_mask, ones])` (:1656-1657) and take the
+        query positions of the last hidden state.  Batched prompts of unequal length come LEFT-padded from the reference's
+        callers (padding_side="left": ddp_sample_coco.py:64, cli_stable_diffusion_pipeline.py:19); positions are the padded
+        indices, as in the reference (default `position_ids`, :950-955)."""
         out = self(input_ids=input_ids, attention_mask=attention_mask, images=images, use_cache=True, return_dict=True)
-        dq = self.model.prepare_dream_queries_with_special_token(input_ids.shape[0]).to(self.dtype)
-        out2 = self.model._forward(inputs_embeds=dq, past_key_values=out.past_key_values, use_cache=False,
+        B = input_ids.shape[0]
+        dq = self.model.prepare_dream_queries_with_special_token(B).to(self.dtype)
+        mask2 = None
+        if attention_mask is not None:
+            mask2 = torch.cat([attention_mask, attention_mask.new_ones(B, dq.shape[1])], dim=1)
+        out2 = self.model._forward(inputs_embeds=dq, attention_mask=mask2, past_key_values=out.past_key_values, use_cache=False,
                                    output_hidden_states=True, return_dict=True)
         return out2.hidden_states[-1][:, 1:-1, :]
 
     @torch.no_grad()
     def stable_diffusion_pipeline(self, prompt_ids, negative_prompt_ids, guidance_scale=7.5, num_inference_steps=50,
                                   height=None, width=None, generator=None, latents=None, output_type="latent",
-                                  guidance_rescale=0.0, **kw):
-        """modeling_dreamllm.py:1766-1880 on token ids (tokenisation is host-side, out of scope)."""
-        prompt_embeds = self.get_prompt_embeds(prompt_ids)
-        negative = self.get_prompt_embeds(negative_prompt_ids) if guidance_scale > 1.0 else None
+                                  guidance_rescale=0.0, prompt_attention_mask=None, negative_prompt_attention_mask=None, **kw):
+        """modeling_dreamllm.py:1766-1880 on token ids (tokenisation is host-side, out of scope); the masks are what the
+        tokenizer returns next to the ids (`tokenizer(prompt, padding=True)`, :1609-1611)."""
+        prompt_embeds = self.get_prompt_embeds(prompt_ids, attention_mask=prompt_attention_mask)
+        negative = None
+        if guidance_scale > 1.0:
+            negative = self.get_prompt_embeds(negative_prompt_ids, attention_mask=negative_prompt_attention_mask)
         return self.stable_diffusion_head.pipeline(
             height=height, width=width, num_inference_steps=num_inference_steps, guidance_scale=guidance_scale,
             generator=generator, latents=latents, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative,

@@ -81,8 +81,12 @@ class PluginBase(ABC, nn.Module, FSDPMixin):
     def _load_bin(self, output_dir) -> bool:
         if check_path_and_file(output_dir, f"{self.save_model_name}.bin"):
             logger.info(f">>> loading `{type(self).__name__}`... from {output_dir}")
-            status = self.load_state_dict(
-                torch.load(os.path.join(output_dir, f"{self.save_model_name}.bin"), map_location="cpu"), strict=False)
+            sd = torch.load(os.path.join(output_dir, f"{self.save_model_name}.bin"), map_location="cpu")
+            # strict, like the reference (modeling_plugins.py:157,296,446): a missing or renamed key must not pass silently.
+            # The one tolerated difference: `...embeddings.position_ids`, a persistent buffer of CLIP towers saved by
+            # transformers < 4.31 that newer towers (and this one) recompute.
+            sd = {k: v for k, v in sd.items() if not k.endswith("embeddings.position_ids")}
+            status = self.load_state_dict(sd, strict=True)
             logger.info(f"{status}")
             return True
         return False

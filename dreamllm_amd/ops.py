@@ -234,8 +234,9 @@ def colsum(dy, out_dtype=torch.bfloat16):
     return d2.sum(dim=0, dtype=torch.float32).to(out_dtype)
 
 
-def attn_fwd(q, k, v, causal, scale=None, seqlens=None, need_lse=True):
-    """q [B,Sq,H,D], k/v [B,Sk,Hkv,D] (any batch/seq/head strides, d contiguous) -> o [B,Sq,H,D], lse [B,H,Sq]."""
+def attn_fwd(q, k, v, causal, scale=None, seqlens=None, need_lse=True, seqstart=None):
+    """q [B,Sq,H,D], k/v [B,Sk,Hkv,D] (any batch/seq/head strides, d contiguous) -> o [B,Sq,H,D], lse [B,H,Sq].
+    seqlens / seqstart (int32 [B] on device): the valid span [start, start + len) of each padded row (see the header)."""
     _need_gpu(q, k, v)
     _bf16(q, k, v)
     B, Sq, H, D = q.shape
@@ -248,13 +249,13 @@ def attn_fwd(q, k, v, causal, scale=None, seqlens=None, need_lse=True):
     scale = scale if scale is not None else 1.0 / math.sqrt(D)
     o = torch.empty(B, Sq, H, D, dtype=q.dtype, device=q.device)
     lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_lse else None
-    check("dllm_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), B, H, Hkv, Sq, Sk, D, q.stride(0), q.stride(1),
+    check("dllm_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), _p(seqstart), B, H, Hkv, Sq, Sk, D, q.stride(0), q.stride(1),
           q.stride(2), k.stride(0), k.stride(1), k.stride(2), o.stride(0), o.stride(1), o.stride(2), float(scale),
           int(causal), _stream())
     return o, lse
 
 
-def attn_bwd(dout, q, k, v, o, lse, causal, scale=None, seqlens=None, dq=None, dk=None, dv=None):
+def attn_bwd(dout, q, k, v, o, lse, causal, scale=None, seqlens=None, dq=None, dk=None, dv=None, seqstart=None):
     """-> dq [B,Sq,H,D], dk/dv [B,Sk,Hkv,D].  dq/dk/dv may be preallocated (strided) views, e.g. slices of one packed
     dQKV buffer; dk and dv must share strides."""
     B, Sq, H, D = q.shape
@@ -274,7 +275,7 @@ def attn_bwd(dout, q, k, v, o, lse, causal, scale=None, seqlens=None, dq=None, d
         raise ValueError("dk and dv must share strides")
     delta = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
     check("dllm_attn_bwd", _p(dout), _p(q), _p(k), _p(v), _p(o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(seqlens),
-          B, H, Hkv, Sq, Sk, D, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
+          _p(seqstart), B, H, Hkv, Sq, Sk, D, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
           o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1),
           dk.stride(2), float(scale), int(causal), _stream())
     return dq, dk, dv
@@ -629,24 +630,24 @@ def rope(q, k, cos, sin, pos=None):
 
 class FlashAttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, causal, scale, seqlens):
+    def forward(ctx, q, k, v, causal, scale, seqlens, seqstart):
         need = q.requires_grad or k.requires_grad or v.requires_grad
-        o, lse = attn_fwd(q, k, v, causal, scale, seqlens, need_lse=need)
+        o, lse = attn_fwd(q, k, v, causal, scale, seqlens, need_lse=need, seqstart=seqstart)
         if need:
-            ctx.save_for_backward(q, k, v, o, lse, seqlens)
+            ctx.save_for_backward(q, k, v, o, lse, seqlens, seqstart)
         ctx.causal, ctx.scale = causal, scale
         return o
 
     @staticmethod
     def backward(ctx, dout):
-        q, k, v, o, lse, seqlens = ctx.saved_tensors
-        dq, dk, dv = attn_bwd(dout, q, k, v, o, lse, ctx.causal, ctx.scale, seqlens)
-        return dq, dk, dv, None, None, None
+        q, k, v, o, lse, seqlens, seqstart = ctx.saved_tensors
+        dq, dk, dv = attn_bwd(dout, q, k, v, o, lse, ctx.causal, ctx.scale, seqlens, seqstart=seqstart)
+        return dq, dk, dv, None, None, None, None
 
 
-def flash_attn(q, k, v, causal=False, scale=None, seqlens=None):
+def flash_attn(q, k, v, causal=False, scale=None, seqlens=None, seqstart=None):
     """q [B,Sq,H,D], k/v [B,Sk,Hkv,D] -> [B,Sq,H,D] (flash_attn_func layout, modeling_dreamllm.py:547-549)."""
-    return FlashAttnFn.apply(q, k, v, causal, scale, seqlens)
+    return FlashAttnFn.apply(q, k, v, causal, scale, seqlens, seqstart)
 
 
 class EmbeddingFn(torch.autograd.Function):
@@ -1056,9 +1057,10 @@ def gemv(x, w, residual=None, out_dtype=torch.bfloat16, out=None):
     return out
 
 
-def attn_decode(q, kcache, vcache, kv_len, scale=None, nsplit=8, out=None):
+def attn_decode(q, kcache, vcache, kv_len, scale=None, nsplit=8, out=None, kv_start=None):
     """q [B,H,D]; kcache/vcache [B,Smax,Hkv,D] (same strides); kv_len int32 [B] ON DEVICE (valid cache length, read by the
-    kernel: the launch does not depend on it) -> [B,H,D]."""
+    kernel: the launch does not depend on it); kv_start int32 [B] on device or None (first valid slot of a left-padded
+    prompt) -> [B,H,D]."""
     _need_gpu(q, kcache, vcache, kv_len)
     _bf16(q, kcache, vcache)
     B, H, D = q.shape
@@ -1070,7 +1072,7 @@ def attn_decode(q, kcache, vcache, kv_len, scale=None, nsplit=8, out=None):
     if out is None:
         out = torch.empty(B, H, D, dtype=q.dtype, device=q.device)
     ws = torch.empty(_lib.lib().dllm_attn_decode_ws_floats(B, H, D, nsplit), dtype=torch.float32, device=q.device)
-    check("dllm_attn_decode", _p(q), _p(kcache), _p(vcache), _p(kv_len), _p(out), _p(ws), B, H, Hkv, D, q.stride(0), q.stride(1),
+    check("dllm_attn_decode", _p(q), _p(kcache), _p(vcache), _p(kv_len), _p(kv_start), _p(out), _p(ws), B, H, Hkv, D, q.stride(0), q.stride(1),
           kcache.stride(0), kcache.stride(1), kcache.stride(2), out.stride(0), out.stride(1),
           float(scale if scale is not None else D ** -0.5), nsplit, _stream())
     return out
@@ -1141,9 +1143,10 @@ def gemv_fused(x, weights, norm_w=None, eps=0.0, residual=None, swiglu=False, ou
     return outs[0] if swiglu else outs
 
 
-def rope_append_(q, k, v, kcache, vcache, cos, sin, pos):
-    """q [B,H,D] rotated in place; k [B,Hkv,D] rotated into kcache[b, pos[b]]; v copied into vcache[b, pos[b]] (pos: int64 [B] on
-    device).  caches [B,Smax,Hkv,D] with identical strides."""
+def rope_append_(q, k, v, kcache, vcache, cos, sin, pos, kv_len=None):
+    """q [B,H,D] rotated in place with rotary position pos[b]; k [B,Hkv,D] rotated into kcache[b, slot]; v copied into
+    vcache[b, slot]; slot = kv_len[b] - 1 (int32 [B] on device) or pos[b] when kv_len is None (pos: int64 [B] on device).
+    caches [B,Smax,Hkv,D] with identical strides."""
     _need_gpu(q, k, v, kcache, vcache, cos, sin, pos)
     _bf16(q, k, v, kcache, vcache)
     B, H, D = q.shape
@@ -1152,6 +1155,6 @@ def rope_append_(q, k, v, kcache, vcache, cos, sin, pos):
         raise ValueError("rope_append_: contiguous q/k/v and equal cache strides required")
     if pos.dtype != torch.int64:
         raise TypeError("rope_append_: pos must be int64")
-    check("dllm_rope_append", _p(q), _p(k), _p(v), _p(kcache), _p(vcache), _p(cos), _p(sin), _p(pos.reshape(-1)), B, H, Hkv, D,
+    check("dllm_rope_append", _p(q), _p(k), _p(v), _p(kcache), _p(vcache), _p(cos), _p(sin), _p(pos.reshape(-1)), _p(kv_len), B, H, Hkv, D,
           q.stride(0), k.stride(0), kcache.stride(0), kcache.stride(1), kcache.stride(2), _stream())
     return q

@@ -19,7 +19,6 @@ class HipAdamW(torch.optim.Optimizer):
         super().__init__(params, defaults)
         self.state_dtype = state_dtype
         self.max_grad_norm = max_grad_norm
-        self._step = 0
         self.last_grad_norm = None  # device scalar (fp32) of the last step, for logging without a sync
 
     def _clip_coef(self):
@@ -37,7 +36,6 @@ class HipAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        self._step += 1
         coef = self._clip_coef() if self.max_grad_norm is not None else None
         for group in self.param_groups:
             b1, b2 = group["betas"]
@@ -49,6 +47,10 @@ class HipAdamW(torch.optim.Optimizer):
                     sd = self.state_dtype or p.dtype
                     st["exp_avg"] = torch.zeros_like(p, dtype=sd, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, dtype=sd, memory_format=torch.preserve_format)
+                    # per-parameter step, kept in `state` like torch.optim.AdamW does (a CPU scalar tensor): it is part of
+                    # state_dict(), so the bias correction resumes where a checkpoint left off
+                    st["step"] = torch.tensor(0.0)
+                st["step"] += 1
                 ops.adamw_(p, p.grad, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
-                           group["weight_decay"], self._step, 1.0, coef)
+                           group["weight_decay"], int(st["step"]), 1.0, coef)
         return loss

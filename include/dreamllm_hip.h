@@ -99,17 +99,19 @@ int dllm_sumpool2_nhwc(const void* in, void* out, int NB, int H, int W, int C, v
 
 /* ---------------------------------------------------------------------------------------------------- attention
  * Flash attention forward: replaces eager attention modeling_dreamllm.py:357-379 and flash_attn_func /
- * flash_attn_varlen_func :532-549 (causal, dropout 0, scale 1/sqrt(Dh), fp32 softmax, right padding via lengths instead
- * of _upad_input :553-583), CLIP self-attention and the UNet self/cross attention [ext].
+ * flash_attn_varlen_func :532-549 (causal, dropout 0, scale 1/sqrt(Dh), fp32 softmax; a padded batch is described by one
+ * contiguous valid span per row -- seqstart[b] (0 if NULL) and seqlens[b] -- instead of _upad_input / pad_input :553-583:
+ * keys outside the span are masked, query rows outside it come back as zeros; with Sq != Sk (KV cache) seqstart masks the
+ * leading keys and every query is valid), CLIP self-attention and the UNet self/cross attention [ext].
  * q,o: [B,Sq,H,D] views (element strides sb,ss,sh; d contiguous); k,v: [B,Sk,Hkv,D] views sharing one stride set;
- * D in {64,128}; H % Hkv == 0 (GQA, repeat_kv :242-251); seqlens int32[B] or NULL; lse fp32 [B,H,Sq] or NULL. */
-int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, int B, int H, int Hkv,
-                  int Sq, int Sk, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
+ * D in {64,128}; H % Hkv == 0 (GQA, repeat_kv :242-251); seqlens / seqstart int32[B] or NULL; lse fp32 [B,H,Sq] or NULL. */
+int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, const int* seqstart, int B,
+                  int H, int Hkv, int Sq, int Sk, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
                   int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale, int causal, void* stream);
 /* its autograd: dq/dk/dv (dk,dv share strides; may alias slices of one packed dQKV buffer); delta fp32 [B,H,Sq] ws. */
 int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* o, const float* lse, float* delta,
-                  void* dq, void* dk, void* dv, const int* seqlens, int B, int H, int Hkv, int Sq, int Sk, int D, int64_t q_sb,
-                  int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
+                  void* dq, void* dk, void* dv, const int* seqlens, const int* seqstart, int B, int H, int Hkv, int Sq, int Sk, int D,
+                  int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
                   int64_t dq_sb, int64_t dq_ss, int64_t dq_sh, int64_t dk_sb, int64_t dk_ss, int64_t dk_sh, float scale,
                   int causal, void* stream);
 
@@ -173,7 +175,9 @@ int dllm_cfg_ddim_step(const void* pred, float* latents, void* next_in, int64_t 
  * dllm_gemv_bf16: one wave per output row, fp32 accumulate, optional fused residual, bf16 or fp32 (logits) output.
  * dllm_attn_decode: softmax(q K^T * scale) V for ONE query token per (b, h) over the cache [B][S_max][Hkv][D]; the valid
  * length kv_len[b] is read from device memory so that the launch is step-invariant (hipGraph replay).  ws: fp32 workspace of
- * dllm_attn_decode_ws_floats(B, H, D, nsplit) elements (split-KV partial softmax states). */
+ * dllm_attn_decode_ws_floats(B, H, D, nsplit) elements (split-KV partial softmax states).  kv_start (int32 [B] on device, or
+ * NULL): first valid cache slot of a LEFT-padded prompt (padding_side="left" callers: omni/eval/vqa/vqa_inference.py:276,
+ * omni/eval/text2img/ddp_sample_coco.py:64); slots [kv_start[b], kv_len[b]) are attended. */
 int dllm_gemv_bf16(const void* x, const void* W, void* y, const void* residual, int M, int64_t N, int64_t K, int64_t ldx,
                    int64_t ldw, int64_t ldy, int64_t ldr, int out_dtype, void* stream);
 /* fused forms that cut the token step from 17 to 7 launches per layer: RMSNorm folded into the GEMV (same roundings as
@@ -182,11 +186,11 @@ int dllm_gemv_fused(const void* x, const void* norm_w, float eps, const void* W0
                     void* y2, const void* residual, int M, int64_t N0, int64_t N1, int64_t N2, int64_t K, int64_t ldx, int64_t ldw,
                     int64_t ldy0, int64_t ldy1, int64_t ldy2, int64_t ldr, int swiglu, int out_dtype, void* stream);
 int dllm_rope_append(void* q, const void* k, const void* v, void* kcache, void* vcache, const float* cos_tab, const float* sin_tab,
-                     const int64_t* pos, int B, int H, int Hkv, int D, int64_t q_sb, int64_t kv_sb, int64_t c_sb, int64_t c_ss,
-                     int64_t c_sh, void* stream);
+                     const int64_t* pos, const int* kv_len, int B, int H, int Hkv, int D, int64_t q_sb, int64_t kv_sb, int64_t c_sb,
+                     int64_t c_ss, int64_t c_sh, void* stream);
 int64_t dllm_attn_decode_ws_floats(int B, int H, int D, int nsplit);
-int dllm_attn_decode(const void* q, const void* kcache, const void* vcache, const int* kv_len, void* out, float* ws, int B, int H,
-                     int Hkv, int D, int64_t q_sb, int64_t q_sh, int64_t c_sb, int64_t c_ss, int64_t c_sh, int64_t o_sb,
+int dllm_attn_decode(const void* q, const void* kcache, const void* vcache, const int* kv_len, const int* kv_start, void* out,
+                     float* ws, int B, int H, int Hkv, int D, int64_t q_sb, int64_t q_sh, int64_t c_sb, int64_t c_ss, int64_t c_sh, int64_t o_sb,
                      int64_t o_sh, float scale, int nsplit, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------- test probes

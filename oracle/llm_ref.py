@@ -185,3 +185,35 @@ def greedy_decode(input_ids, sd, cfg, steps):
         logits = F.linear(h[:, -1], sd["lm_head.weight"]).float()
         ids = torch.cat([ids, logits.argmax(-1, keepdim=True)], dim=1)
     return ids
+
+
+def random_state_dict(cfg, seed=0, n_added=0, added_boost=1.0):
+    """Seeded DreamLLM decoder weights (bf16-representable fp32, reference key names, no plugin keys) -- reproducible on any
+    host, so fixtures for configurations with a full-size vocabulary store the seed instead of 8 MB of embeddings.
+    `added_boost` scales the lm_head rows of the last `n_added` (special) tokens: with a boost > 1 they win most argmaxes
+    unless the decode loop slices the logits to the base vocabulary (omni/eval/language_eval/modeling_dreamllm.py:79,86)."""
+    g = torch.Generator().manual_seed(seed)
+    H, F_, V, L = cfg["hidden_size"], cfg["intermediate_size"], cfg["vocab_size"], cfg["num_hidden_layers"]
+    nh, nkv = cfg["num_attention_heads"], cfg.get("num_key_value_heads") or cfg["num_attention_heads"]
+    hd = H // nh
+    r16 = lambda t: t.to(torch.bfloat16).to(torch.float32)
+    w = lambda *s: r16(torch.randn(*s, generator=g) * 0.05)
+    n = lambda s: r16(1.0 + 0.1 * torch.randn(s, generator=g))
+    sd = {"model.embed_tokens.weight": w(V, H)}
+    for i in range(L):
+        p = f"model.layers.{i}."
+        sd[p + "self_attn.q_proj.weight"] = w(nh * hd, H)
+        sd[p + "self_attn.k_proj.weight"] = w(nkv * hd, H)
+        sd[p + "self_attn.v_proj.weight"] = w(nkv * hd, H)
+        sd[p + "self_attn.o_proj.weight"] = w(H, nh * hd)
+        sd[p + "mlp.gate_proj.weight"] = w(F_, H)
+        sd[p + "mlp.up_proj.weight"] = w(F_, H)
+        sd[p + "mlp.down_proj.weight"] = w(H, F_)
+        sd[p + "input_layernorm.weight"] = n(H)
+        sd[p + "post_attention_layernorm.weight"] = n(H)
+    sd["model.norm.weight"] = n(H)
+    head = w(V, H)
+    if n_added:
+        head[V - n_added:] = r16(head[V - n_added:] * added_boost)
+    sd["lm_head.weight"] = head
+    return sd

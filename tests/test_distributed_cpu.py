@@ -146,3 +146,90 @@ def test_sharded_grad_adamw_matches_single_process_adamw():
     assert torch.allclose(torch.tensor(n0), torch.tensor(norms), rtol=1e-5)
     n_params = sum(p.numel() for p in params)
     assert sb0 == sb1 and sb0 <= 2 * 4 * (n_params // 2 + 4)  # two fp32 moments over half the parameters (+ padding)
+
+
+def _resume_worker(rank, world, port, q):
+    """3 steps straight vs 2 steps -> state_dict -> fresh optimizer + load_state_dict -> 1 step (param groups: no decay on biases)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dreamllm_amd import distributed as D
+    D.init_distributed("gloo")
+    data = torch.arange(80, dtype=torch.float32).view(10, 8) / 80.0
+    x = data[list(D.shard_for_rank(10))]
+
+    def make():
+        torch.manual_seed(0)
+        model = torch.nn.Sequential(torch.nn.Linear(8, 13), torch.nn.Tanh(), torch.nn.Linear(13, 3))
+        groups = [{"params": [p for n, p in model.named_parameters() if n.endswith("weight")], "weight_decay": 0.1},
+                  {"params": [p for n, p in model.named_parameters() if n.endswith("bias")], "weight_decay": 0.0}]
+        opt = D.ShardedGradAdamW(groups, lr=1e-2, betas=(0.9, 0.95), max_grad_norm=0.5, bucket_mb=1, update_fn=_torch_adamw,
+                                 sumsq_fn=_sumsq)
+        return model, opt
+
+    def run(model, opt, n):
+        for _ in range(n):
+            opt.zero_grad()
+            model(x).pow(2).mean().backward()
+            opt.step()
+
+    m1, o1 = make()
+    run(m1, o1, 3)
+    m2, o2 = make()
+    run(m2, o2, 2)
+    sd, weights = o2.state_dict(), [p.detach().clone() for p in m2.parameters()]
+    m3, o3 = make()
+    with torch.no_grad():
+        for p, w in zip(m3.parameters(), weights):
+            p.copy_(w)  # parameters come from the model checkpoint; they stay views of the flat buffers
+    o3.load_state_dict(sd)
+    run(m3, o3, 1)
+    a = torch.cat([p.detach().flatten() for p in m1.parameters()])
+    b = torch.cat([p.detach().flatten() for p in m3.parameters()])
+    bad = None
+    try:
+        o3.load_state_dict(dict(sd, world=4))
+    except ValueError as e:
+        bad = str(e)
+    q.put((rank, a.tolist(), b.tolist(), sorted(set(o1.bucket_wd)), bad is not None, sd["step"]))
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_grad_adamw_checkpoint_resume_and_param_groups():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_resume_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for _, a, b, wds, refused, step in res:
+        assert a == b, "resumed run must reproduce the uninterrupted one bit for bit (step + moments round-trip)"
+        assert wds == [0.0, 0.1] and refused and step == 2
+
+
+def test_decay_param_groups_and_plugin_aware_save(tmp_path):
+    """`decay_param_groups`: RMSNorm weights / biases out of weight decay (omni/train/trainer.py:388-411);
+    `save_dreamllm_full_state_dict`: pytorch_model.bin + one {save_model_name}.bin per plugin with the prefix stripped
+    (omni/utils/fsdp_utils.py:23-61)."""
+    from dreamllm_amd import distributed as D
+    from dreamllm_amd.configuration_dreamllm import DreamLLMConfig
+    from dreamllm_amd.modeling_dreamllm import DreamLLMForCausalMLM
+    from dreamllm_amd.modeling_plugins import DreamEmbedding
+    cfg = DreamLLMConfig(vocab_size=64, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+                         max_position_embeddings=32)
+    lm = DreamLLMForCausalMLM(cfg)
+    lm.model.dream_embedding = DreamEmbedding(num_dream_queries=4, embed_hidden_size=128)
+    lm.config.plugins_type["dream_embedding"] = "embedding"
+    groups = D.decay_param_groups(lm, 0.05)
+    names = {id(p): n for n, p in lm.named_parameters()}
+    nod = {names[id(p)] for p in groups[1]["params"]}
+    assert groups[0]["weight_decay"] == 0.05 and groups[1]["weight_decay"] == 0.0
+    assert nod == {n for n in names.values() if "layernorm" in n or n == "model.norm.weight"}
+    saved = D.save_dreamllm_full_state_dict(lm, str(tmp_path), rank=0)
+    assert saved == ["dream_embedding"]
+    full = torch.load(tmp_path / "pytorch_model.bin")
+    plug = torch.load(tmp_path / "dream_embedding.bin")
+    assert "model.dream_embedding.dream_queries" in full and list(plug) == ["dream_queries"]
+    assert torch.equal(plug["dream_queries"], lm.model.dream_embedding.dream_queries.data)
