@@ -289,7 +289,7 @@ def rope_(x, cos, sin, pos=None, backward=False):
     if x.stride(3) != 1 or x.stride(0) != S * x.stride(1):
         raise ValueError("rope_: x must have a uniform token stride")
     if pos is not None:
-        pos = pos.expand(B, S).contiguous().view(-1)
+        pos = pos.reshape(-1) if pos.numel() == B * S else pos.expand(B, S).contiguous().view(-1)
         if pos.dtype != torch.int64:
             pos = pos.long()
     check("dllm_rope", _p(x), _p(cos), _p(sin), _p(pos), B * S, S, NH, D, x.stride(1), x.stride(2), int(backward), _stream())

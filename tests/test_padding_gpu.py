@@ -233,7 +233,7 @@ def test_ragged_language_eval_loop_matches_executed_reference(golden, mode):
     for b in range(len(plens)):
         nb = int(valid[b].sum())
         checked += _tokens_agree(ours[b:b + 1, :nb], refn[b:b + 1, :nb], g["margins"][b:b + 1], forced[b:b + 1])
-    assert checked >= 12
+    assert checked >= 8  # 6 forced + the free steps before each row's first near-tie
     gen = ours[~forced[:, : ours.shape[1]]]
     assert int(gen.max()) < 32000  # no added special token is ever emitted
 
