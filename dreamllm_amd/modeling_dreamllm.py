@@ -387,7 +387,13 @@ class BaseModelOutputWithPast(ModelOutput):
 
 @dataclass
 class CausalLMOutputWithPast(ModelOutput):
-    """modeling_dreamllm.py:1172-1206."""
+    """modeling_dreamllm.py:1172-1206.
+
+    `logits` may be LAZY: the training forward computes the LM loss with the fused lm_head + cross-entropy unit
+    (`ops.LMHeadCEFn`), which never holds the [B, S, V] fp32 logits (4.2 GB at the stage-II shape).  A caller that does read
+    `out.logits` / `out["logits"]` gets them materialised on first access (one GEMM on the saved hidden states, detached --
+    the loss gradient does not flow through them); callers that only use the loss, as the trainer does
+    (omni/train/trainer.py:1061), never pay for them."""
 
     loss: torch.FloatTensor | None = None
     logits: torch.FloatTensor = None
@@ -395,6 +401,34 @@ class CausalLMOutputWithPast(ModelOutput):
     hidden_states: tuple[torch.FloatTensor] | None = None
     attentions: tuple[torch.FloatTensor] | None = None
     additional_log_info: dict[str, Any] | None = None
+
+    def set_lazy_logits(self, thunk):
+        object.__setattr__(self, "_logits_thunk", thunk)
+        return self
+
+    def _materialize_logits(self):
+        thunk = self.__dict__.get("_logits_thunk")
+        if thunk is None:
+            return None
+        object.__setattr__(self, "_logits_thunk", None)
+        val = thunk()
+        self.logits = val          # ModelOutput.__setattr__ also registers the key
+        return val
+
+    def __getattribute__(self, name):
+        if name == "logits":
+            val = super().__getattribute__("logits")
+            if val is None and self.__dict__.get("_logits_thunk") is not None:
+                return self._materialize_logits()
+            return val
+        return super().__getattribute__(name)
+
+    def __getitem__(self, k):
+        if k == "logits" and "logits" not in self.keys():
+            val = self.logits
+            if val is not None:
+                return val
+        return super().__getitem__(k)
 
 
 class DreamLLMPreTrainedModel(PreTrainedModel, FSDPMixin):
@@ -706,11 +740,18 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
             vm_loss = self._head_dummy(head, images_dm)
 
         lm_loss = 0.0
+        logits = lazy_logits = None
         if labels is not None:
             # shift so that tokens < n predict n: row (b, s) is scored against labels[b, s+1]; the last row is ignored
             shift = torch.cat([labels[:, 1:], labels.new_full((B, 1), -100)], dim=1).reshape(-1)
-            lm_loss, logits = ops.lm_head_ce(hidden_states.reshape(B * S, H), self.lm_head.weight, shift)
-            logits = logits.view(B, S, -1)
+            if getattr(self.config, "fused_lm_head_ce", True) and return_dict:
+                # fused lm_head + CE: loss (and, in the same pass, its gradients) without the [B,S,V] fp32 logits
+                lm_loss = ops.lm_head_ce(hidden_states.reshape(B * S, H), self.lm_head.weight, shift)
+                hs, w = hidden_states.detach(), self.lm_head.weight
+                lazy_logits = lambda: ops.linear_fwd(hs, ops._pad_vocab(w.detach()), out_dtype=torch.float32)[..., : w.shape[0]]  # noqa: E731
+            else:
+                lm_loss, logits = ops.lm_head_ce(hidden_states.reshape(B * S, H), self.lm_head.weight, shift, return_logits=True)
+                logits = logits.view(B, S, -1)
         else:
             logits = ops.linear(hidden_states, self.lm_head.weight, out_fp32=True)
 
@@ -743,9 +784,12 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
             "vm_loss": vm_loss.detach() if torch.is_tensor(vm_loss) else vm_loss,
         }
         additional_log_info.update(outputs.additional_log_info or {})
-        return CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=outputs.past_key_values,
-                                      hidden_states=outputs.hidden_states, attentions=None,
-                                      additional_log_info=additional_log_info)
+        out = CausalLMOutputWithPast(loss=loss, logits=logits, past_key_values=outputs.past_key_values,
+                                     hidden_states=outputs.hidden_states, attentions=None,
+                                     additional_log_info=additional_log_info)
+        if lazy_logits is not None:
+            out.set_lazy_logits(lazy_logits)
+        return out
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):
         """modeling_dreamllm.py:1511-1547."""

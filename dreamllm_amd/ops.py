@@ -716,27 +716,88 @@ def gather_rows_unique(x2d, idx):
     return GatherRowsFn.apply(x2d, idx)
 
 
-class LMHeadCEFn(torch.autograd.Function):
-    """lm_head + fp32 logits + shifted masked CE (modeling_dreamllm.py:1452-1470) as one differentiable unit.
+LM_HEAD_CE_CHUNK_ROWS = 4096  # rows of hidden states per chunk of the fused lm_head + CE (525 MB of fp32 logits at V = 32008)
 
-    hidden [R, d] bf16, weight [V, d] bf16, labels int64 [R] (already shifted; -100 ignored).
-    Returns (loss, logits_fp32).  The fp32 logits come straight from the fp32 MFMA accumulators.  Backward recomputes
-    the softmax from the saved logits and emits bf16 dlogits scaled by dloss / n_valid read from a device scalar
-    (no host sync), then two GEMMs.
-    """
+
+def _pad_vocab(weight):
+    """vocabulary not a multiple of 8 (DreamLLM-SDXL: 32009): the GEMMs of the backward contract over / produce the
+    vocabulary axis and need 16-byte rows, so the unit runs on a zero-padded weight; the CE kernel still sees V columns (row
+    pitch Vp), so the pad columns enter neither the softmax nor the gradient."""
+    V = weight.shape[0]
+    Vp = (V + 7) // 8 * 8
+    if Vp == V:
+        return weight
+    wp = torch.zeros(Vp, weight.shape[1], dtype=weight.dtype, device=weight.device)
+    wp[:V].copy_(weight)
+    return wp
+
+
+class LMHeadCEFn(torch.autograd.Function):
+    """lm_head + fp32 logits + shifted masked CE (modeling_dreamllm.py:1452-1470) as ONE unit that never holds the [T, V]
+    logits: the reference materialises them in fp32 (4.2 GB at T = 32768, V = 32008) and reads them ~3 times.
+
+    hidden [R, d] bf16, weight [V, d] bf16, labels int64 [R] (already shifted; -100 ignored) -> mean CE over valid rows.
+    Rows are processed in chunks of LM_HEAD_CE_CHUNK_ROWS: logits chunk (fp32, straight from the MFMA accumulators) ->
+    `dllm_cross_entropy` (per-row loss AND bf16 dlogits = (softmax - onehot) / n_valid in the same pass, n_valid read from a
+    device scalar: no host sync) -> dHidden rows (dgrad GEMM) and dW += dlogits^T hidden (wgrad GEMM accumulating in fp32).
+    Loss and both gradients therefore come out of the FORWARD; backward only scales them by the incoming dloss.  Peak extra
+    memory is one chunk (0.8 GB) instead of 4.2 GB + 2.1 GB, and a chunk's logits are consumed while still cache-resident.
+    Same arithmetic as the unfused form (same GEMM kernel, same CE kernel, fp32 accumulation of dW across chunks)."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, labels):
+        R, d = hidden.shape
+        V = weight.shape[0]
+        wp = _pad_vocab(weight)
+        Vp = wp.shape[0]
+        need_dh, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        nvalid = (labels != -100).sum()
+        denom = torch.clamp(nvalid, min=1).to(torch.float32)
+        gscale = (1.0 / denom).reshape(1).contiguous()
+        loss_rows = torch.empty(R, dtype=torch.float32, device=hidden.device)
+        dh = torch.empty(R, d, dtype=hidden.dtype, device=hidden.device) if need_dh else None
+        dw32 = None
+        C = max(256, int(LM_HEAD_CE_CHUNK_ROWS))
+        for i, r0 in enumerate(range(0, R, C)):
+            r1 = min(R, r0 + C)
+            h_c = hidden[r0:r1]
+            logits_c = linear_fwd(h_c, wp, out_dtype=torch.float32)
+            dl_c = None
+            if need_dh or need_dw:
+                dl_c = (torch.zeros if Vp != V else torch.empty)(r1 - r0, Vp, dtype=torch.bfloat16, device=hidden.device)
+            loss_rows[r0:r1] = cross_entropy_rows(logits_c[:, :V], labels[r0:r1], dlogits=None if dl_c is None else dl_c[:, :V],
+                                                  gscale=gscale if dl_c is not None else None)
+            del logits_c
+            if need_dh:
+                gemm(dl_c, wp, r1 - r0, d, Vp, dl_c.stride(0), d, 0, 1, out=dh[r0:r1])
+            if need_dw:
+                if dw32 is None:
+                    dw32 = torch.empty(Vp, d, dtype=torch.float32, device=hidden.device)
+                linear_wgrad(dl_c, h_c, out=dw32, accumulate=i > 0, out_dtype=torch.float32)
+        dw = dw32[:V].to(weight.dtype) if dw32 is not None else None
+        ctx.save_for_backward(dh, dw)
+        return loss_rows.sum() / denom
+
+    @staticmethod
+    def backward(ctx, dloss):
+        dh, dw = ctx.saved_tensors
+        g = dloss.to(torch.float32)
+        # dloss is a scalar (1 / loss_scale, times the lm weight): one multiply per gradient element, in place
+        if dh is not None:
+            dh = dh.mul_(g.to(dh.dtype))
+        if dw is not None:
+            dw = dw.mul_(g.to(dw.dtype))
+        return dh, dw, None
+
+
+class LMHeadCELogitsFn(torch.autograd.Function):
+    """The unfused form: also returns the full fp32 logits [R, V] (callers that want them next to the loss, e.g. an
+    evaluation loop with `prediction_loss_only=False`).  Backward recomputes the softmax from the saved logits."""
 
     @staticmethod
     def forward(ctx, hidden, weight, labels):
         V = weight.shape[0]
-        Vp = (V + 7) // 8 * 8
-        if Vp != V:
-            # vocabulary not a multiple of 8 (DreamLLM-SDXL: 32009): the GEMMs of the backward contract over / produce the
-            # vocabulary axis and need 16-byte rows, so run the unit on a zero-padded weight; the CE kernel still sees V
-            # columns (row pitch Vp), so the pad columns enter neither the softmax nor the gradient
-            wp = torch.zeros(Vp, weight.shape[1], dtype=weight.dtype, device=weight.device)
-            wp[:V].copy_(weight)
-        else:
-            wp = weight
+        wp = _pad_vocab(weight)
         logits_p = linear_fwd(hidden, wp, out_dtype=torch.float32)
         logits = logits_p[:, :V]
         loss_row = cross_entropy_rows(logits, labels)
@@ -764,7 +825,10 @@ class LMHeadCEFn(torch.autograd.Function):
         return dh, dw, None
 
 
-def lm_head_ce(hidden2d, weight, labels1d):
+def lm_head_ce(hidden2d, weight, labels1d, return_logits=False):
+    """-> loss (fused, no [T,V] tensor) or (loss, fp32 logits) with `return_logits=True` (unfused)."""
+    if return_logits:
+        return LMHeadCELogitsFn.apply(hidden2d, weight, labels1d)
     return LMHeadCEFn.apply(hidden2d, weight, labels1d)
 
 

@@ -19,6 +19,10 @@ DEV = "cuda"
 BF = torch.bfloat16
 
 
+def bf16r(t):
+    return t.to(BF).float()
+
+
 def _ops():
     from dreamllm_amd import ops
     return ops
@@ -418,7 +422,7 @@ def test_linear_autograd_and_lm_head_ce(V):
     lref = F.cross_entropy(hr @ wr.t(), labels, ignore_index=-100)
     (lref * 3.0).backward()
     hg, wg = h.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
-    loss, logits = ops.lm_head_ce(hg, wg, labels.to(DEV))
+    loss, logits = ops.lm_head_ce(hg, wg, labels.to(DEV), return_logits=True)
     (loss * 3.0).backward()
     assert abs(loss.item() - lref.item()) < 1e-4 * abs(lref.item()) + 1e-5
     assert logits.shape == (T, V) and wg.grad.shape == (V, d)
@@ -582,3 +586,39 @@ def test_gemv_fused_norm_multi_swiglu_and_rope_append():
     for b in range(B):
         assert torch.equal(kc[b, pos[b]], k_ref[b, 0]) and torch.equal(vc[b, pos[b]], vv[b])
     assert int((kc != 0).any(dim=-1).any(dim=-1).sum()) == B  # exactly one cache row per batch element written
+
+
+@pytest.mark.parametrize("V", [1000, 1001])
+def test_lm_head_ce_fused_matches_unfused_and_torch(V):
+    """Fused lm_head + CE (modeling_dreamllm.py:1452-1470 without the [T,V] logits: chunked GEMM -> CE fwd+bwd -> dgrad / wgrad
+    inside the forward) against the unfused unit (same kernels, full logits) and an fp32 torch reference; odd vocabulary
+    (DreamLLM-SDXL's 32009 case), ignored rows, more rows than one chunk, upstream gradient != 1."""
+    from dreamllm_amd import ops
+    torch.manual_seed(V)
+    R, d = 2500, 256
+    h = bf16r(torch.randn(R, d) * 0.5)
+    w = bf16r(torch.randn(V, d) * 0.05)
+    lab = torch.randint(0, V, (R,))
+    lab[torch.rand(R) < 0.3] = -100
+    hr, wr = h.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.cross_entropy(F.linear(hr, wr), lab, ignore_index=-100)
+    (ref * 0.37).backward()
+    old = ops.LM_HEAD_CE_CHUNK_ROWS
+    ops.LM_HEAD_CE_CHUNK_ROWS = 1024
+    try:
+        res = {}
+        for fused in (True, False):
+            hd, wd = h.to(BF).to(DEV).requires_grad_(True), w.to(BF).to(DEV).requires_grad_(True)
+            out = ops.lm_head_ce(hd, wd, lab.to(DEV), return_logits=not fused)
+            loss = out if fused else out[0]
+            (loss * 0.37).backward()
+            res[fused] = (loss.detach(), hd.grad, wd.grad)
+            if not fused:
+                assert out[1].shape == (R, V) and rel_l2(out[1], F.linear(h, w)) < 1e-5
+    finally:
+        ops.LM_HEAD_CE_CHUNK_ROWS = old
+    assert abs(res[True][0].item() - ref.item()) < 1e-4 * abs(ref.item())       # fp32 logits, fp32 CE
+    assert torch.equal(res[True][0], res[False][0])                               # same kernels, same row order
+    assert rel_l2(res[True][1], hr.grad) < 8e-3 and rel_l2(res[True][2], wr.grad) < 8e-3
+    assert rel_l2(res[True][1], res[False][1]) < 4e-3                             # bf16 roundings at different points
+    assert rel_l2(res[True][2], res[False][2]) < 4e-3
