@@ -17,6 +17,10 @@ LIB = os.path.join(HERE, "libdreamllm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
          "-Wno-unused-result", "-Wno-pass-failed"]
+# DLLM_BENCH_MODES=1 python -m dreamllm_amd.build --force : additionally compiles the wrong-result diagnostic GEMM modes used by
+# tools/gemm_ksweep.py (never part of the shipped library; rebuild with --force afterwards)
+if os.environ.get("DLLM_BENCH_MODES") == "1":
+    FLAGS.append("-DDLLM_BENCH_MODES")
 
 
 def _sources():

@@ -475,14 +475,9 @@ int launch_bwd(const AttnParams& P, hipStream_t stream) {
     constexpr int KT = (D == 128) ? 1 : 2;
     constexpr int LDS_DQ = 2 * 2 * 64 * D * 2;
     constexpr int LDS_DKV = 2 * (2 * 64 * D * 2 + 512);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<D, CAUSAL, QT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DQ);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<D, CAUSAL, KT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DKV);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0}, lds2_ok{0};
+    dllm_ensure_dyn_lds(&attn_bwd_dq_kernel<D, CAUSAL, QT>, LDS_DQ, lds_ok);
+    dllm_ensure_dyn_lds(&attn_bwd_dkv_kernel<D, CAUSAL, KT>, LDS_DKV, lds2_ok);
     const int64_t rows = (int64_t)P.B * P.Sq * P.H;
     const int64_t nthreads = rows * (D / 8);
     hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, P);

@@ -221,12 +221,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 template <int D, bool CAUSAL>
 int launch_fwd(const AttnParams& P, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * 64 * D * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<D, CAUSAL>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    dllm_ensure_dyn_lds(&attn_fwd_kernel<D, CAUSAL>, LDS, lds_ok);
     dim3 grid((P.Sq + 127) / 128, P.H, P.B);
     hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL>), grid, dim3(256), LDS, stream, P);
     return dllm_check_launch();

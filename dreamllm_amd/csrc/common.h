@@ -97,3 +97,17 @@ static inline int dllm_check_launch() {
 }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// One-time, per-device opt-in to more than 64 KiB of dynamic LDS for a kernel.  Thread-safe (autograd's backward thread and
+// the main thread both launch) and per device (one bit per ordinal): the only process-level state of this library, and it is
+// idempotent -- two racing threads both set the same attribute.
+#include <atomic>
+template <typename K>
+static inline void dllm_ensure_dyn_lds(K kernel, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}

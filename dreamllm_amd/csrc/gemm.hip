@@ -33,11 +33,28 @@ constexpr int B_K = 0, B_N = 1;
 
 constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
 
-static int g_force_tile = 0;  // test/benchmark override: 0 auto, 128, 256
-static int g_dbg_noload = 0;
-static int g_group_m = 0;   // 0: per-layout default (4 for k-contiguous A, 8 for the weight-gradient layout); else forced
-static int g_glds_pipe = 1;   // software-pipelined direct-to-LDS kernel (default); 0 = plain direct-to-LDS kernel (tile mode 257/258)
-static int g_use_glds = 1;    // direct-to-LDS 256-tile kernel when eligible
+// Kernel choice is a per-call argument (`variant`, see include/dreamllm_hip.h): the library keeps no mutable state.
+struct Variant {
+    int force_tile = 0;  // 0 auto, 128, 256
+    int use_glds = 1;    // direct-to-LDS 256-tile kernel when eligible
+    int glds_pipe = 1;   // software-pipelined direct-to-LDS kernel (default); 0 = plain direct-to-LDS kernel
+    int dbg_noload = 0;  // benchmark-only wrong-result modes; compiled in with -DDLLM_BENCH_MODES only
+    int group_m = 0;     // 0: per-layout default
+};
+static inline int parse_variant(int variant, Variant& v) {
+    const int tile = variant & 0xffff;
+    v.group_m = (variant >> 16) & 0xff;
+    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259;
+#ifdef DLLM_BENCH_MODES
+    ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265;
+    v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
+#endif
+    if (!ok || (variant >> 24) != 0) return DLLM_ERR_SHAPE;
+    v.use_glds = (tile == 0 || tile >= 257);
+    v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 263 || tile == 265);
+    v.force_tile = tile >= 257 ? 256 : tile;
+    return DLLM_OK;
+}
 
 struct ConvGeom {
     int H, W, C;     // physical input spatial dims and channels (NHWC)
@@ -1015,12 +1032,8 @@ int launch_gemm_t(const GemmParams& P, hipStream_t stream) {
     const int64_t tiles = cdiv64(P.M, T) * cdiv64(P.N, T);
     if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
     constexpr int LDS = 2 * 2 * T * BK * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<AL, BL, T>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    dllm_ensure_dyn_lds(&gemm_bf16_kernel<AL, BL, T>, LDS, lds_ok);
     const int sk = P.splitk > 1 ? P.splitk : 1;
     hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, T>), dim3((unsigned)tiles, sk), dim3(2 * T), LDS, stream, P);
     if (sk > 1) {
@@ -1041,25 +1054,21 @@ static inline double tile_eff(int64_t M, int64_t N, int T, double speed) {
 }
 
 template <int AL, int BL>
-int launch_gemm(const GemmParams& P, hipStream_t stream) {
+int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     if (P.M <= 0 || P.N <= 0) return DLLM_OK;
     const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);
-    bool glds_ok = g_use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K);
+    bool glds_ok = V.use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K);
     if (AL == A_CONV)  // LDS-DMA gather: plain geometry, a K tile inside one tap, pipelined kernel only
-        glds_ok = glds_ok && g_glds_pipe && (P.cv.C % BK) == 0 && !P.cv.up_shift && !P.cv.even_only && BL == B_K;
+        glds_ok = glds_ok && V.glds_pipe && (P.cv.C % BK) == 0 && !P.cv.up_shift && !P.cv.even_only && BL == B_K;
     const bool pick256 = tile_eff(P.M, P.N, 256, glds_ok ? 1.15 : 1.0) >= tile_eff(P.M, P.N, 128, 0.85);
     if (P.splitk > 1) return launch_gemm_t<AL, BL, 128>(P, stream);
-    if (g_force_tile == 256 || (g_force_tile == 0 && pick256)) {
+    if (V.force_tile == 256 || (V.force_tile == 0 && pick256)) {
         if constexpr (AL == A_CONV) {
             if constexpr (BL == B_K) {
                 if (glds_ok) {
                     constexpr int LDS = 2 * 2 * 256 * BK * 2;
-                    static bool attr_set = false;
-                    if (!attr_set) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<AL, BL>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-                        attr_set = true;
-                    }
+                    static std::atomic<uint64_t> lds_ok{0};
+                    dllm_ensure_dyn_lds(&gemm_pipe_kernel<AL, BL>, LDS, lds_ok);
                     hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);
                     return dllm_check_launch();
                 }
@@ -1068,19 +1077,10 @@ int launch_gemm(const GemmParams& P, hipStream_t stream) {
         if constexpr (AL != A_CONV) {
             if (glds_ok) {
                 constexpr int LDS = 2 * 2 * 256 * BK * 2;
-                static bool attr_set = false;
-                if (!attr_set) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds_kernel<AL, BL>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-                    attr_set = true;
-                }
-                if (g_glds_pipe) {
-                    static bool attr2_set = false;
-                    if (!attr2_set) {
-                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_pipe_kernel<AL, BL>),
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-                        attr2_set = true;
-                    }
+                static std::atomic<uint64_t> lds_ok{0}, lds2_ok{0};
+                dllm_ensure_dyn_lds(&gemm_glds_kernel<AL, BL>, LDS, lds_ok);
+                if (V.glds_pipe) {
+                    dllm_ensure_dyn_lds(&gemm_pipe_kernel<AL, BL>, LDS, lds2_ok);
                     hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);
                     return dllm_check_launch();
                 }
@@ -1104,19 +1104,21 @@ extern "C" {
 // epi: 0 none, 1 exact-erf GELU, 2 quick-GELU, 3 SiLU.  out_dtype: DLLM_BF16 / DLLM_F32.
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
-                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, void* stream);
+                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int variant, void* stream);
 
 int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
                    int out_dtype, int accumulate, float alpha, void* stream) {
     return dllm_gemm_bf16_splitk(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, layout_a, layout_b, epi, out_dtype,
-                                 accumulate, alpha, 1, nullptr, stream);
+                                 accumulate, alpha, 1, nullptr, 0, stream);
 }
 
 // splitk > 1: workspace = fp32 [splitk][M][N] (caller-allocated); requires N % 4 == 0.
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
-                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, void* stream) {
+                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int variant, void* stream) {
+    Variant V;
+    if (parse_variant(variant, V) != DLLM_OK) return DLLM_ERR_SHAPE;
     if (splitk > 1 && (workspace == nullptr || (N & 3))) return DLLM_ERR_SHAPE;
     if (M < 0 || N < 0 || K < 0) return DLLM_ERR_SHAPE;
     if (M == 0 || N == 0) return DLLM_OK;
@@ -1131,15 +1133,15 @@ int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bia
     P.A = (const bf16*)A; P.B = (const bf16*)B; P.C = C; P.bias = (const bf16*)bias; P.residual = (const bf16*)residual;
     P.M = M; P.N = N; P.K = K; P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldr = ldr;
     P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = accumulate; P.alpha = alpha;
-    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.dbg_noload = g_dbg_noload;
+    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.dbg_noload = V.dbg_noload;
     // grouped tile order: M rows per column group.  Measured (tools/gemm_groupm_sweep.py): 2-4 is 2-5 % faster than 8 for the
     // forward / input-gradient layouts (A = activations, M = 32768), 8 is best for the weight gradient; 16+ loses 10 %.
-    P.group_m = g_group_m > 0 ? g_group_m : (layout_a == A_M ? 8 : 4);
+    P.group_m = V.group_m > 0 ? V.group_m : (layout_a == A_M ? 8 : 4);
     hipStream_t s = (hipStream_t)stream;
-    if (layout_a == A_K && layout_b == B_K) return launch_gemm<A_K, B_K>(P, s);
-    if (layout_a == A_K && layout_b == B_N) return launch_gemm<A_K, B_N>(P, s);
-    if (layout_a == A_M && layout_b == B_N) return launch_gemm<A_M, B_N>(P, s);
-    if (layout_a == A_M && layout_b == B_K) return launch_gemm<A_M, B_K>(P, s);
+    if (layout_a == A_K && layout_b == B_K) return launch_gemm<A_K, B_K>(P, V, s);
+    if (layout_a == A_K && layout_b == B_N) return launch_gemm<A_K, B_N>(P, V, s);
+    if (layout_a == A_M && layout_b == B_N) return launch_gemm<A_M, B_N>(P, V, s);
+    if (layout_a == A_M && layout_b == B_K) return launch_gemm<A_M, B_K>(P, V, s);
     return DLLM_ERR_SHAPE;
 }
 
@@ -1157,25 +1159,6 @@ int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K) {
     return s < 2 ? 1 : (int)s;
 }
 
-// tile-size override for tests / microbenchmarks (0 = automatic)
-int dllm_gemm_set_tile(int tile) {
-    if (tile >= 1000 && tile < 1100) {  // benchmark knob: 1000 + GROUP_M of the grouped tile order
-        g_group_m = tile - 1000;  // 1000: back to the per-layout default
-        return DLLM_OK;
-    }
-    // 0 auto, 128, 256 (register-staged 256 tile), 257 = 256 tile with the direct-to-LDS kernel where eligible
-    // 258: like 257 but WITHOUT the K-loop prefetches (wrong results; exposes the compute+barrier ceiling in microbenchmarks)
-    // 259: 257 with the software-pipelined kernel; 260: 259 without the K-loop prefetches (benchmark only)
-    // 263: 259 with every prefetch reading K tile 0 (wrong results; all loads hit in L2: isolates the DMA path from HBM/L2 misses)
-    // 265: 259 without the C stores (benchmark only)
-    if (tile != 0 && tile != 128 && (tile < 256 || tile > 260) && tile != 263 && tile != 265) return DLLM_ERR_SHAPE;
-    g_use_glds = (tile == 0 || tile >= 257);
-    g_glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 263 || tile == 265);
-    g_dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
-    g_force_tile = tile >= 257 ? 256 : tile;
-    return DLLM_OK;
-}
-
 // NHWC convolution as implicit GEMM: out[n,oh,ow,co] = sum_{kh,kw,ci} in[n,ih,iw,ci] * w[co,kh,kw,ci] (+bias, +residual).
 // x: [NB,H,W,C] bf16, w: [CO, KH*KW*C] bf16 (k-contiguous), out: [NB,OH,OW,CO].
 // up2: the logical input is the nearest-2x upsampling of x (Upsample2D + conv fused).
@@ -1184,20 +1167,22 @@ int dllm_gemm_set_tile(int tile) {
 int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
                                  const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                                  int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,
-                                 float* workspace, void* stream);
+                                 float* workspace, int variant, void* stream);
 
 int dllm_conv2d_nhwc_bf16(const void* x, const void* w, void* out, const void* bias, const void* residual,
                           const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                           int stride, int pad, int up2, int even_only, int epi, int out_dtype, void* stream) {
     return dllm_conv2d_nhwc_bf16_splitk(x, w, out, bias, residual, image_bias, NB, H, W, C, OH, OW, CO, KH, KW, stride, pad, up2,
-                                        even_only, epi, out_dtype, 1, nullptr, stream);
+                                        even_only, epi, out_dtype, 1, nullptr, 0, stream);
 }
 
 // splitk > 1: workspace = fp32 [splitk][NB*OH*OW][CO]; requires CO % 4 == 0.
 int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
                                  const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                                  int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,
-                                 float* workspace, void* stream) {
+                                 float* workspace, int variant, void* stream) {
+    Variant V;
+    if (parse_variant(variant, V) != DLLM_OK) return DLLM_ERR_SHAPE;
     if (splitk > 1 && (workspace == nullptr || (CO & 3))) return DLLM_ERR_SHAPE;
     if (NB < 0 || H <= 0 || W <= 0 || C <= 0 || CO <= 0 || OH <= 0 || OW <= 0) return DLLM_ERR_SHAPE;
     if (NB == 0) return DLLM_OK;
@@ -1210,10 +1195,10 @@ int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const 
     P.lda = C; P.ldb = P.K; P.ldc = CO; P.ldr = CO;
     P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = 0; P.alpha = 1.0f;
     P.rg_bias = (const bf16*)image_bias; P.rg_rows = (int64_t)OH * OW;
-    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.dbg_noload = g_dbg_noload;
-    P.group_m = g_group_m > 0 ? g_group_m : 4;  // output pixels are the M dimension (activations), as in the forward GEMMs
+    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.dbg_noload = V.dbg_noload;
+    P.group_m = V.group_m > 0 ? V.group_m : 4;  // output pixels are the M dimension (activations), as in the forward GEMMs
     P.cv = ConvGeom{H, W, C, OH, OW, KH, KW, stride, pad, up2, even_only};
-    return launch_gemm<A_CONV, B_K>(P, (hipStream_t)stream);
+    return launch_gemm<A_CONV, B_K>(P, V, (hipStream_t)stream);
 }
 
 }  // extern "C"

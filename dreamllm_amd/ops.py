@@ -49,6 +49,25 @@ EPI = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3}
 
 SPLITK = True  # split-K for small grids with deep reductions (see dllm_gemm_splitk_hint)
 
+# Kernel variant handed to every GEMM / conv launch (include/dreamllm_hip.h `variant`): 0 = automatic.  Python-side knob for
+# tests and microbenchmarks (`with ops.gemm_variant(259): ...`); the C library itself keeps no state.
+GEMM_VARIANT = 0
+
+
+class gemm_variant:
+    def __init__(self, tile=0, group_m=0):
+        self.v = int(tile) | (int(group_m) << 16)
+
+    def __enter__(self):
+        global GEMM_VARIANT
+        self.prev, GEMM_VARIANT = GEMM_VARIANT, self.v
+        return self
+
+    def __exit__(self, *exc):
+        global GEMM_VARIANT
+        GEMM_VARIANT = self.prev
+        return False
+
 # bench.py sets this to a list to time every launch of the MFMA GEMM/conv kernel with HIP events recorded on the stream the
 # kernel is launched on (torch's current stream): entries are (start_event, end_event, flops, tag).
 GEMM_PROFILE = None
@@ -183,7 +202,7 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     with _GemmTimer(2.0 * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
         check("dllm_gemm_bf16_splitk", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
               ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),
-              sk, _p(ws), _stream())
+              sk, _p(ws), GEMM_VARIANT, _stream())
     return out
 
 
@@ -852,7 +871,7 @@ def conv2d_nhwc(x, w2d, CO, KH, KW, stride=1, pad=1, OH=None, OW=None, bias=None
     ws = torch.empty(sk * Mg * CO, dtype=torch.float32, device=x.device) if sk > 1 else None
     with _GemmTimer(2.0 * N * OH * OW * CO * KH * KW * C, "conv"):
         check("dllm_conv2d_nhwc_bf16_splitk", _p(x), _p(w2d), _p(out), _p(bias), _p(residual), _p(image_bias), N, H, W, C, OH,
-              OW, CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), sk, _p(ws), _stream())
+              OW, CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), sk, _p(ws), GEMM_VARIANT, _stream())
     return out
 
 

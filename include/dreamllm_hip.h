@@ -74,19 +74,19 @@ int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, cons
 /* Split-K variants for small grids with deep reductions (UNet at batch 2): splitk > 1 writes fp32 partials to the caller's
  * workspace [splitk][M][N] and a deterministic reduce kernel applies the epilogue.  dllm_gemm_splitk_hint suggests splitk. */
 int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K);
+/* `variant` selects the kernel PER CALL (the library holds no mutable state; every entry point is re-entrant and may be called
+ * from any thread on any stream): low 16 bits = tile family -- 0 automatic (what the product passes), 128 / 256 register-staged
+ * tiles, 257 plain LDS-DMA 256-tile kernel, 259 software-pipelined LDS-DMA kernel (the automatic choice for eligible shapes);
+ * bits 16-23 = GROUP_M of the grouped tile order (0 = per-layout default).  Tests pass 128 / 256 / 257 / 259 to cover every
+ * kernel family.  Anything else returns DLLM_ERR_SHAPE.  (A build with -DDLLM_BENCH_MODES additionally accepts the
+ * wrong-result diagnostic modes 258 / 260 / 263 / 265 used by tools/; the shipped library does not contain them.) */
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
-                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, void* stream);
+                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int variant, void* stream);
 int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
                                  const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                                  int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,
-                                 float* workspace, void* stream);
-/* Kernel-variant override for tests / microbenchmarks ONLY (process-global, not thread-safe; the product path never calls it):
- * 0 automatic; 128 / 256 register-staged tiles; 257 plain LDS-DMA 256-tile kernel; 259 software-pipelined LDS-DMA kernel (the
- * default for eligible shapes); 258 / 260 the same without K-loop prefetches, 263 every prefetch re-reads K tile 0, 265 no C
- * stores (these three give wrong results by design: they bracket the cost of the memory path); 1000 + g sets GROUP_M = g of
- * the grouped tile order (1000 restores the per-layout default).  Returns DLLM_ERR_SHAPE for anything else. */
-int dllm_gemm_set_tile(int tile);
+                                 float* workspace, int variant, void* stream);
 /* NHWC convolution (3x3 / 1x1) as implicit GEMM: ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D, Upsample2D,
  * conv_in/conv_out of UNet2DConditionModel and AutoencoderKL [ext] (call sites modeling_plugins.py:511,556,815-821,842).
  * x [NB,H,W,C] bf16, w [CO][KH*KW*C] bf16 (k = (kh,kw,ci)), out [NB,OH,OW,CO]; image_bias [NB,CO] = per-image

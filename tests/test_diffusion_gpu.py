@@ -37,8 +37,8 @@ def test_conv_fwd_dgrad(N, H, W, CI, CO, K, mode, tile):
     """Implicit-GEMM NHWC conv against F.conv2d (fp32, NCHW) incl. stride-2, fused nearest-upsample, asymmetric pad,
     channel-padded conv_in / 4-channel conv_out; input gradient through the flipped-weight conv."""
     from dreamllm_amd.unet import HipConv2d, _pad8
-    from dreamllm_amd import _lib
-    _lib.check("dllm_gemm_set_tile", tile)
+    from dreamllm_amd import ops as _o
+    _o.GEMM_VARIANT = tile  # per-call kernel variant (restored below)
     torch.manual_seed(N * H + CI + CO)
     conv = HipConv2d(CI, CO, K, mode=mode)
     conv.weight.data = bf16r(conv.weight.data)
@@ -67,7 +67,7 @@ def test_conv_fwd_dgrad(N, H, W, CI, CO, K, mode, tile):
     if mode != "down_asym":
         y.backward(dy.permute(0, 2, 3, 1).contiguous().to(BF).to(DEV))
         assert rel_l2(xd.grad[..., :CI].permute(0, 3, 1, 2), xr.grad) < 4e-3
-    _lib.check("dllm_gemm_set_tile", 0)
+    _o.GEMM_VARIANT = 0
 
 
 def test_conv_epilogue_image_bias_and_residual():

@@ -142,10 +142,9 @@ def test_layernorm_fwd_bwd(rows, D):
 @pytest.fixture(params=[128, 256, 257, 259])
 def gemm_tile(request):
     """run the GEMM tests once per block-tile variant (128x128 / 4 waves and 256x256 / 8 waves)"""
-    from dreamllm_amd import _lib
-    _lib.check("dllm_gemm_set_tile", request.param)
-    yield request.param
-    _lib.check("dllm_gemm_set_tile", 0)
+    from dreamllm_amd import ops
+    with ops.gemm_variant(request.param):
+        yield request.param
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 512), (130, 200, 264), (1, 64, 8), (777, 1000, 1032),

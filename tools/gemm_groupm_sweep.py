@@ -16,7 +16,7 @@ ten = {}
 for name, N, K in shapes:
     ten[name] = (torch.randn(M, K, device="cuda").to(BF), (torch.randn(N, K, device="cuda") * 0.02).to(BF), torch.randn(M, N, device="cuda").to(BF))
 for gm in (8, 4, 16, 2, 32, 8):
-    _lib.check("dllm_gemm_set_tile", 1000 + gm)
+    ops.GEMM_VARIANT = gm << 16  # GROUP_M rides in bits 16-23 of the per-call variant
     out = []
     for name, N, K in shapes:
         x, w, dy = ten[name]

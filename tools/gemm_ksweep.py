@@ -14,7 +14,7 @@ ap.add_argument("--tile", type=int, default=0)
 ap.add_argument("--M", type=int, default=32768)
 ap.add_argument("--N", type=int, default=4096)
 a = ap.parse_args()
-_lib.check("dllm_gemm_set_tile", a.tile)
+ops.GEMM_VARIANT = a.tile  # per-call kernel variant (diagnostic modes 258/260/263/265 need a -DDLLM_BENCH_MODES build)
 BF = torch.bfloat16
 M, N = a.M, a.N
 res = []

@@ -190,7 +190,7 @@ def main():
     a = ap.parse_args()
     sel = set(a.only.split(",")) if a.only else None
     from dreamllm_amd import _lib
-    _lib.check("dllm_gemm_set_tile", a.tile)
+    ops.GEMM_VARIANT = a.tile  # per-call kernel variant
     if a.out and os.path.exists(a.out):
         os.remove(a.out)
     benches = dict(conv=bench_conv, norm=bench_norm, elementwise=bench_elementwise, attn=bench_attn, attn_bwd=bench_attn_bwd, gemm=bench_gemm, gemv=bench_gemv)
