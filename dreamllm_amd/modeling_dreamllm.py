@@ -18,6 +18,7 @@ Same class names, constructor kwargs, forward signatures, output dataclasses and
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Any
 
@@ -670,6 +671,48 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
             if self.config.plugins_type[name] == "head":
                 ignored_modules += getattr(self, name).fsdp_ignored_modules()
         return ignored_modules
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, tokenizer=None, *model_args, config=None, cache_dir=None,
+                        ignore_mismatched_sizes: bool = False, force_download: bool = False, local_files_only: bool = False,
+                        token=None, revision: str = "main", use_safetensors: bool = None,
+                        reset_plugin_model_name_or_path: bool = False, **kwargs):
+        """modeling_dreamllm.py:1244-1333 -- the positional `tokenizer` override that `projects/dreamllm/train.py:130-137`
+        calls: load the LLM weights (an initial LLaMA/Vicuna checkpoint or an exported DreamLLM one), grow the embeddings to
+        the tokenizer's vocabulary, point every plugin without an explicit checkpoint at the model folder, and only then
+        build the plugins (`init_plugin_modules`, after the resize so `_init_weights` cannot touch them, :1328-1329).
+
+        `use_flash_attention_2` (train.py:135) is accepted and ignored: the flash kernels are the only attention path here,
+        so the reference's ImportError for a missing flash_attn wheel (:706-710) cannot occur."""
+        assert tokenizer is not None, "tokenizer should not be None"
+        kwargs.pop("use_flash_attention_2", None)
+        kwargs.pop("attn_implementation", None)
+        if config is None or isinstance(config, (str, os.PathLike)):
+            config_path = config if config is not None else pretrained_model_name_or_path
+            config = cls.config_class.from_pretrained(config_path, cache_dir=cache_dir, force_download=force_download,
+                                                      local_files_only=local_files_only, token=token, revision=revision)
+        model = super().from_pretrained(pretrained_model_name_or_path, *model_args, config=config, cache_dir=cache_dir,
+                                        ignore_mismatched_sizes=ignore_mismatched_sizes, force_download=force_download,
+                                        local_files_only=local_files_only, token=token, revision=revision,
+                                        use_safetensors=use_safetensors, **kwargs)
+        config = model.config
+        if reset_plugin_model_name_or_path:
+            config.reset_plugins_init_kwargs()
+        if len(tokenizer) > model.config.vocab_size:
+            logger.info(f"The tokenizer vocabulary size {len(tokenizer)} is larger than the model vocabulary size "
+                        f"{model.config.vocab_size}. Resizing token embedding of model...")
+            model.resize_token_embeddings(len(tokenizer))
+            model.vocab_size = model.model.vocab_size = len(tokenizer)
+        elif len(tokenizer) < model.config.vocab_size:
+            logger.warning(f"The tokenizer vocabulary size {len(tokenizer)} is smaller than the model vocabulary size "
+                           f"{model.config.vocab_size}. Carefully check the configuration to avoid potential issues.")
+        logger.info(f"Now, the tokenizer and model vocabulary sizes are both {len(tokenizer)}.")
+        # HACK (reference): add all pretrained plugins path if not specified
+        for _, init_kwargs in config.plugins_init_kwargs.items():
+            if init_kwargs.get("pretrained_model_name_or_path", None) is None:
+                init_kwargs["pretrained_model_name_or_path"] = pretrained_model_name_or_path
+        model.init_plugin_modules()
+        return model
 
     def get_input_embeddings(self):
         return self.model.embed_tokens

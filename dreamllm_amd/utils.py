@@ -156,3 +156,13 @@ def deep_instantiate(cfg):
             return cls(**kw)
         return {k: deep_instantiate(v) for k, v in cfg.items()}
     return cfg
+
+
+def average_init_token_embeddings(model, num_added_tokens: int):
+    """omni/utils/tokenizer_utils.py:70-80: newly added token rows of the input and output embeddings start at the mean of the
+    existing rows (train.py:142-146)."""
+    assert num_added_tokens > 0, "`num_added_tokens` should be positive"
+    input_embeddings = model.get_input_embeddings().weight.data
+    output_embeddings = model.get_output_embeddings().weight.data
+    input_embeddings[-num_added_tokens:] = input_embeddings[:-num_added_tokens].mean(dim=0, keepdim=True)
+    output_embeddings[-num_added_tokens:] = output_embeddings[:-num_added_tokens].mean(dim=0, keepdim=True)

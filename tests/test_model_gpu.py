@@ -361,3 +361,34 @@ def test_causal_mlm_sdxl_golden(golden):
     lm.zero_grad(set_to_none=True)
     out2 = lm(images_dm=None, add_time_ids=None, **kw)
     check_scalar("causal_mlm_sdxl.loss_dummy", out2.loss, g["loss_dummy"], er["loss_dummy"]["abs_err"])
+
+
+def test_collator_indices_match_the_model_path(golden):
+    """The data bridge (dreamllm_amd/data.py): a batch collated from per-sample dicts, carrying seqlens / dream_index /
+    image_index, gives bit-identical loss and logits to the same batch without them (the model then derives the slots and the
+    spans from input_ids / attention_mask on the device)."""
+    from types import SimpleNamespace
+    from dreamllm_amd.data import DataCollatorForDreamLLMDataset
+    g = golden("causal_mlm.pt")
+    lm = _build_lm(g).train()
+    am = g["attention_mask"]
+    ids = g["input_ids"]
+    sp = lm.config.special_tokens2ids_dict["additional_special_tokens"]
+    exs, ic, dc = [], 0, 0
+    for b in range(ids.shape[0]):
+        n = int(am[b].sum())
+        ni = int((ids[b, :n] == sp["<im_start>"]).sum())
+        nd = int((ids[b, :n] == sp["<dream_start>"]).sum())
+        exs.append(dict(input_ids=ids[b, :n], attention_mask=am[b, :n], labels=g["labels"][b, :n],
+                        images=g["images"][ic:ic + ni] if ni else None, images_dm=g["images_dm"][dc:dc + nd] if nd else None))
+        ic, dc = ic + ni, dc + nd
+    col = DataCollatorForDreamLLMDataset.from_model(SimpleNamespace(pad_token_id=int(ids[1, -1])), lm)
+    assert (col.n_dream, col.n_patch) == (4, 6)
+    batch = col(exs)
+    assert torch.equal(batch["input_ids"], ids) and torch.equal(batch["labels"], g["labels"])
+    dev = lambda v: v.to(DEV) if torch.is_tensor(v) and not v.is_floating_point() else (v.to(BF).to(DEV) if torch.is_tensor(v) else v)
+    full = {k: dev(v) for k, v in batch.items()}
+    a = lm(**full, return_dict=True)
+    bare = {k: v for k, v in full.items() if k not in ("seqlens", "dream_index", "image_index")}
+    b = lm(**bare, return_dict=True)
+    assert torch.equal(a.loss, b.loss) and torch.equal(a.logits, b.logits)
