@@ -155,6 +155,47 @@ __global__ __launch_bounds__(256) void segment_sum_rows_kernel(const bf16* __res
     }
 }
 
+// Row softmax of fp32 scores -> bf16 probabilities (the single-head 512-wide VAE mid-block attention, whose head_dim is outside
+// the flash kernels: scores come from the GEMM kernel in fp32, probabilities go back into it as the A operand of P V).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, bf16* __restrict__ y, int cols, int64_t ld_x,
+                                                           int64_t ld_y) {
+    __shared__ float scratch[4];
+    const float* row = x + (int64_t)blockIdx.x * ld_x;
+    bf16* out = y + (int64_t)blockIdx.x * ld_y;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+        if (c + 3 < cols) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        } else {
+            for (int e = c; e < cols; ++e) mx = fmaxf(mx, row[e]);
+        }
+    }
+    mx = block_max<4>(mx, scratch);
+    float se = 0.f;
+    for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+        if (c + 3 < cols) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            se += __expf(v[0] - mx) + __expf(v[1] - mx) + __expf(v[2] - mx) + __expf(v[3] - mx);
+        } else {
+            for (int e = c; e < cols; ++e) se += __expf(row[e] - mx);
+        }
+    }
+    se = block_sum<4>(se, scratch);
+    const float inv = 1.0f / se;
+    for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+        if (c + 3 < cols) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (bf16)(__expf(v[e] - mx) * inv);
+            st_bf16x4(out + c, o);
+        } else {
+            for (int e = c; e < cols; ++e) out[e] = (bf16)(__expf(row[e] - mx) * inv);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ softmax cross-entropy over fp32 logits
 // (modeling_dreamllm.py:1453-1470: logits.float(), CrossEntropyLoss(reduction="none"), mean over labels != -100).
 // One block per row.  loss_row[r] = lse - logit[label] (0 for ignored rows);  dlogits (bf16, optional) =
@@ -501,6 +542,14 @@ int dllm_segment_sum_rows(const void* dy, const int64_t* order, const int64_t* s
     const int g = (int)(nuniq < 4096 ? nuniq : 4096);
     hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, order, seg_start,
                        uid, (bf16*)dtable, nuniq, D, ld_dy, ld_t);
+    return dllm_check_launch();
+}
+
+// softmax over the last dimension: x fp32 [rows][cols] (row pitch ld_x, multiple of 4) -> y bf16 (row pitch ld_y, multiple of 4)
+int dllm_softmax_rows(const float* x, void* y, int64_t rows, int cols, int64_t ld_x, int64_t ld_y, void* stream) {
+    if (rows < 0 || cols <= 0 || (ld_x & 3) || (ld_y & 3)) return DLLM_ERR_SHAPE;
+    if (rows == 0) return DLLM_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, cols, ld_x, ld_y);
     return dllm_check_launch();
 }
 

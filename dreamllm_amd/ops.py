@@ -392,6 +392,38 @@ def cross_entropy_rows(logits, labels, dlogits=None, gscale=None):
     return loss_row
 
 
+def softmax_rows(x):
+    """softmax over the last dim of fp32 x [..., C] -> bf16 (block-per-row kernel)."""
+    _need_gpu(x)
+    if x.dtype != torch.float32:
+        raise TypeError("softmax_rows expects fp32 scores")
+    C = x.shape[-1]
+    x2 = x.reshape(-1, C)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    y = torch.empty(x2.shape, dtype=torch.bfloat16, device=x.device)
+    check("dllm_softmax_rows", _p(x2), _p(y), x2.shape[0], C, x2.stride(0), y.stride(0), _stream())
+    return y.view(x.shape)
+
+
+def attention_wide_head(q, k, v, scale=None):
+    """softmax(q k^T * scale) v for ONE head of any width (multiple of 8): q [N,Sq,C], k/v [N,Sk,C] bf16 -> [N,Sq,C].
+    Two MFMA GEMMs around a row-softmax kernel; the [Sq,Sk] scores are materialised in fp32 (64 MB at 4096 tokens), which is
+    what the VAE mid-block attention needs once per image and the flash kernels (head_dim 64 / 128) cannot serve."""
+    _need_gpu(q, k, v)
+    _bf16(q, k, v)
+    N, Sq, C = q.shape
+    Sk = k.shape[1]
+    scale = scale if scale is not None else 1.0 / math.sqrt(C)
+    out = torch.empty(N, Sq, C, dtype=q.dtype, device=q.device)
+    for n in range(N):
+        qn, kn, vn = q[n].contiguous(), k[n].contiguous(), v[n].contiguous()
+        s = gemm(qn, kn, Sq, Sk, C, C, C, 0, 0, out_dtype=torch.float32, alpha=scale)
+        p = softmax_rows(s)
+        gemm(p, vn, Sq, C, Sk, Sk, C, 0, 1, out=out[n])
+    return out
+
+
 def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, grad_scale_dev=None):
     _need_gpu(p, g, m, v)
     if g.dtype != p.dtype:

@@ -5,7 +5,8 @@ omni/models/dreamllm/modeling_plugins.py:375,511-512,842.  diffusers state_dict 
 SURVEY.md lists the VAE as "stock PyTorch for now / next row (f2)"; it already runs on this package's HIP kernels because
 every piece exists: NHWC implicit-GEMM conv (incl. the encoder's asymmetric-pad stride-2 downsample and the decoder's
 fused nearest-upsample conv), GroupNorm(+SiLU).  The single-head 512-wide mid-block attention (head_dim 512, outside the
-flash kernel's 64/128) uses torch's scaled_dot_product_attention.  Frozen => no backward.
+flash kernel's 64/128) runs as GEMM -> row softmax (`dllm_softmax_rows`) -> GEMM (`ops.attention_wide_head`).  Frozen => no
+backward.
 """
 from __future__ import annotations
 
@@ -74,8 +75,8 @@ class _Attn(nn.Module):
         res = x.reshape(N, H * W, C)
         h = self.group_norm(x).reshape(N, H * W, C)
         q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
-        o = torch.nn.functional.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]  # 1 head, dim 512
-        return self.to_out[0](o.contiguous(), residual=res).reshape(N, H, W, C)
+        o = ops.attention_wide_head(q, k, v)  # 1 head of width C = 512: two MFMA GEMMs around the row-softmax kernel
+        return self.to_out[0](o, residual=res).reshape(N, H, W, C)
 
 
 class _Sampler(nn.Module):

@@ -621,3 +621,17 @@ def test_lm_head_ce_fused_matches_unfused_and_torch(V):
     assert rel_l2(res[True][1], hr.grad) < 8e-3 and rel_l2(res[True][2], wr.grad) < 8e-3
     assert rel_l2(res[True][1], res[False][1]) < 4e-3                             # bf16 roundings at different points
     assert rel_l2(res[True][2], res[False][2]) < 4e-3
+
+
+@pytest.mark.parametrize("N,Sq,Sk,C", [(2, 256, 256, 64), (1, 1024, 1024, 512), (1, 100, 72, 128)])
+def test_wide_head_attention_and_row_softmax(N, Sq, Sk, C):
+    """`ops.attention_wide_head` (GEMM -> `dllm_softmax_rows` -> GEMM): the VAE mid-block attention, one head of width 512."""
+    from dreamllm_amd import ops
+    torch.manual_seed(C)
+    q, k, v = bf16r(torch.randn(N, Sq, C)), bf16r(torch.randn(N, Sk, C)), bf16r(torch.randn(N, Sk, C))
+    ref = F.scaled_dot_product_attention(q[:, None], k[:, None], v[:, None])[:, 0]
+    out = ops.attention_wide_head(q.to(BF).to(DEV), k.to(BF).to(DEV), v.to(BF).to(DEV))
+    assert rel_l2(out, ref) < 6e-3
+    x = torch.randn(37, 1003, device=DEV) * 3
+    x4 = torch.nn.functional.pad(x, (0, 1))[:, :1004]  # pitch multiple of 4
+    assert rel_l2(ops.softmax_rows(x4[:, :1000].contiguous()), torch.softmax(x4[:, :1000].float(), -1).cpu()) < 4e-3
