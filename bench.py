@@ -46,18 +46,22 @@ def parse():
     ap.add_argument("--no-denoise", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short config-2 / config-5 legs (N = 1 only)")
     ap.add_argument("--sharded-grad", action="store_true",
                     help="N>1: reduce-scatter + sharded AdamW + all-gather (distributed.ShardedGradAdamW) instead of DDP all-reduce")
     return ap.parse_args()
 
 
 def cpu_baseline(seq_len):
-    """Oracle (`oracle/llm_ref.py`, kind "port") timed on the host cores: one Vicuna-7B decoder layer forward+backward at
-    B=1, fp32, scaled by the 32 layers + lm_head/CE to a full-model sample.  Bounded to a few tens of seconds."""
-    from oracle import llm_ref
+    """Oracle (`oracle/*_ref.py`, kind "port") timed on the host cores (baseline only): (i) one Vicuna-7B decoder
+    layer forward+backward at B=1, S=seq_len, fp32, x32 layers + lm_head/CE; (ii) the CLIP-ViT-L/14 encoder forward on one
+    image (x K_c = 2, frozen: forward only); (iii) the restated SD-2.1 UNet on one CFG batch (2 x [4,64,64], 64 context tokens):
+    its time is the CPU denoise step, and 2 x forward stands for the training pass (forward + input gradient) of each of the
+    K_g = 2 dream images.  Bounded to ~20-30 s of CPU work: every piece is run once after a short warm-up piece."""
+    from oracle import llm_ref, unet_ref
     torch.manual_seed(0)
     H, Fd, nh = 4096, 11008, 32
-    S = min(seq_len, 1024)  # bounded sample: 1024 tokens of one sequence
+    S = seq_len
     sd = {}
     for n, shp in (("self_attn.q_proj.weight", (H, H)), ("self_attn.k_proj.weight", (H, H)), ("self_attn.v_proj.weight", (H, H)),
                    ("self_attn.o_proj.weight", (H, H)), ("mlp.gate_proj.weight", (Fd, H)), ("mlp.up_proj.weight", (Fd, H)),
@@ -67,29 +71,52 @@ def cpu_baseline(seq_len):
     sd["post_attention_layernorm.weight"] = torch.ones(H, requires_grad=True)
     cfg = dict(num_attention_heads=nh, num_key_value_heads=nh, rms_norm_eps=1e-6)
     cos, sin = llm_ref.rope_tables(H // nh, S)
-    x = torch.randn(1, S, H, requires_grad=True)
     mask = llm_ref.causal_mask_4d(None, 1, S, torch.float32)
     pos = torch.arange(S)[None]
 
-    def one():
-        y = llm_ref.decoder_layer(x, sd, "", cfg, cos, sin, pos, mask)
-        y.square().mean().backward()
+    def layer(x):
+        llm_ref.decoder_layer(x, sd, "", cfg, cos, sin, pos, mask).square().mean().backward()
 
-    one()  # warm-up
+    layer(torch.randn(1, S, H, requires_grad=True)[:, :S])  # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
-    one()
+    layer(torch.randn(1, S, H, requires_grad=True))
     t_layer = time.perf_counter() - t0
-    # lm_head + CE forward/backward on the same tokens
     w = (torch.randn(32008, H) * 0.02).requires_grad_(True)
     h = torch.randn(S, H, requires_grad=True)
     lab = torch.randint(0, 32008, (S,))
     t0 = time.perf_counter()
     torch.nn.functional.cross_entropy((h @ w.t()).float(), lab).backward()
     t_head = time.perf_counter() - t0
-    tokens_per_s = S / (32 * t_layer + t_head)
-    return dict(value=tokens_per_s / seq_len, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle/llm_ref decoder layer fwd+bwd, fp32, B=1 S={S} (x32 layers) + lm_head/CE; CLIP/UNet/VAE share "
-                       f"(4% of FLOPs) not included; host has {os.cpu_count()} logical cores")
+    del sd, w, h, mask
+    # (ii) CLIP-ViT-L/14 forward, one image
+    t_clip = None
+    try:  # the installed transformers CLIPVisionModel: the class the reference wraps (modeling_plugins.py:214-219)
+        from transformers import CLIPVisionConfig, CLIPVisionModel
+        clip = CLIPVisionModel(CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
+                                                num_attention_heads=16, image_size=224, patch_size=14)).eval()
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            clip(torch.randn(1, 3, 224, 224), output_hidden_states=True)
+            t_clip = time.perf_counter() - t0
+        del clip
+    except Exception:  # the CLIP share is 0.4 % of the sample's FLOPs: report without it rather than fail
+        t_clip = None
+    # (iii) restated SD-2.1 UNet, one CFG step (batch 2) at 64x64 latents
+    ucfg = dict(unet_ref.SD21_BASE)
+    usd = unet_ref.random_state_dict(ucfg, seed=0)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        unet_ref.unet_forward(torch.randn(2, 4, 64, 64), torch.tensor([500]), torch.randn(2, 64, 1024), usd, ucfg)
+        t_unet2 = time.perf_counter() - t0
+    del usd
+    K = 2
+    t_sample = 32 * t_layer + t_head + K * (t_clip or 0.0) + K * t_unet2  # K_g images x (fwd + dgrad ~ 2 fwd) = K x one batch-2 fwd x 2 / 2
+    return dict(value=1.0 / t_sample, unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                denoise_steps_per_s=round(1.0 / t_unet2, 4),
+                sample=f"oracle ports (CLIP: installed transformers class), fp32, one piece each: decoder layer fwd+bwd B=1 S={S} ({t_layer:.2f} s, x32) + lm_head/CE "
+                       f"({t_head:.2f} s) + CLIP-L/14 fwd ({'n/a' if t_clip is None else f'{t_clip:.2f} s'}, x{K}) + SD-2.1 UNet CFG "
+                       f"step batch 2 ({t_unet2:.2f} s = the CPU denoise step; x{K} stands for fwd+dgrad of {K} dream images); "
+                       f"VAE not included; host has {os.cpu_count()} logical cores")
 
 
 def main():
@@ -105,7 +132,7 @@ def main():
     dev = torch.device("cuda", local)
 
     from dreamllm_amd import distributed as D, ops
-    from dreamllm_amd.factory import TINY, VICUNA_7B, build_dreamllm
+    from dreamllm_amd.factory import TINY, TINY_CLIP, TINY_DIFFUSION, VICUNA_7B, build_dreamllm
     from dreamllm_amd.optim import HipAdamW
     from dreamllm_amd.schedulers import DDIMScheduler
     from dreamllm_amd.synthetic import make_interleaved_batch
@@ -113,12 +140,7 @@ def main():
     D.init_distributed("nccl")
     tiny = a.model == "tiny"
     if tiny:
-        from oracle import unet_ref
-        model = build_dreamllm(TINY, device=dev, clip=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3,
-                                                           num_attention_heads=2, image_size=56),
-                               diffusion=dict(unet=unet_ref.tiny_config(64), vae=dict(block_out_channels=(32, 64, 64, 64),
-                                                                                      layers_per_block=1)),
-                               num_dream_queries=8)
+        model = build_dreamllm(TINY, device=dev, clip=TINY_CLIP, diffusion=TINY_DIFFUSION, num_dream_queries=8)
     else:
         model = build_dreamllm(VICUNA_7B, device=dev)
     head = model.stable_diffusion_head
@@ -127,27 +149,38 @@ def main():
     # ------------------------------------------------------------------ M2: SD-2.1 512 px denoise steps/s (replicas)
     denoise = None
     if not a.no_denoise:
-        Bi = a.denoise_batch
         nq = model.model.dream_embedding.embed_len
-        g = torch.Generator().manual_seed(42)
-        pe = (torch.randn(Bi, nq, model.config.hidden_size, generator=g) * 0.02).to(dev, torch.bfloat16)
-        ne = (torch.randn(Bi, nq, model.config.hidden_size, generator=g) * 0.02).to(dev, torch.bfloat16)
-        sched = DDIMScheduler()
-        kw = dict(num_inference_steps=a.denoise_steps, guidance_scale=7.5, prompt_embeds=pe, negative_prompt_embeds=ne,
-                  output_type="latent", scheduler=sched)
-        if tiny:
-            kw.update(height=128, width=128)
-        head.pipeline(generator=torch.Generator().manual_seed(42), **{**kw, "num_inference_steps": 2})  # warm-up
-        D.synchronize()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        head.pipeline(generator=torch.Generator().manual_seed(42), **kw)
-        torch.cuda.synchronize()
-        dt = D.max_over_ranks(time.perf_counter() - t0)
-        sps = world * a.denoise_steps / dt
-        denoise = dict(metric="SD-2.1 512px denoise steps/s (50 DDIM eta=0, CFG 7.5, replicas)", value=round(sps, 3),
-                       unit="steps/s", batch_images=Bi, unet_batch=2 * Bi, ms_per_step=round(1e3 * dt / a.denoise_steps, 3),
-                       frac_mfma_peak=None if tiny else round(sps / world * 2 * Bi * FLOPS_UNET_FWD / (PEAK_BF16_TFLOPS * 1e12), 4))
+        legs = []
+        for Bi in ([a.denoise_batch] if a.denoise_batch != 1 else ([1] if (tiny or world > 1) else [1, 8])):  # B_img in {1, 8}
+            g = torch.Generator().manual_seed(42)
+            pe = (torch.randn(Bi, nq, model.config.hidden_size, generator=g) * 0.02).to(dev, torch.bfloat16)
+            ne = (torch.randn(Bi, nq, model.config.hidden_size, generator=g) * 0.02).to(dev, torch.bfloat16)
+            sched = DDIMScheduler()
+            kw = dict(num_inference_steps=a.denoise_steps, guidance_scale=7.5, prompt_embeds=pe, negative_prompt_embeds=ne,
+                      output_type="latent", scheduler=sched)
+            if tiny:
+                kw.update(height=128, width=128)
+            head.pipeline(generator=torch.Generator().manual_seed(42), **{**kw, "num_inference_steps": 2})  # warm-up + graph capture
+            D.synchronize()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            head.pipeline(generator=torch.Generator().manual_seed(42), **kw)
+            torch.cuda.synchronize()
+            dt = D.max_over_ranks(time.perf_counter() - t0)
+            sps = world * a.denoise_steps / dt
+            tf = sps / world * 2 * Bi * FLOPS_UNET_FWD / 1e12
+            legs.append(dict(
+                metric="SD-2.1 512px denoise steps/s (50 DDIM eta=0, CFG 7.5, replicas)", value=round(sps, 3), unit="steps/s",
+                batch_images=Bi, unet_batch=2 * Bi, ms_per_step=round(1e3 * dt / a.denoise_steps, 3),
+                roofline=None if tiny else dict(
+                    bound="mfma", kernel="SD-2.1 UNet forward (conv + GEMM + attention launches of one step, hipGraph replay)",
+                    achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_TFLOPS, 4), traffic=None,
+                    note="achieved = algorithmic 2*B_img*0.803 TFLOP per step / measured step time (whole loop body: the launches "
+                         "live inside one hipGraph replay, so per-launch HIP events do not apply); kernel-level shares: "
+                         "profiles/r02_denoise_kernel_stats.csv")))
+        denoise = dict(legs[0], legs=legs) if legs else None
+        if denoise is not None and not tiny:
+            denoise["frac_mfma_peak"] = legs[0]["roofline"]["frac"]
 
     # ------------------------------------------------------------------ M1: interleaved train samples/s
     train = {}
@@ -217,8 +250,9 @@ def main():
                 fwd = next(v for k, v in tj["per_launch"].items() if k.startswith("fwd"))
                 traffic = int(tj.get("gemm_bf16_kernel_hbm_bytes_per_launch") or fwd["hbm_bytes_corrected"])
                 traffic_detail = {"shape": tj.get("shape"), "algorithmic_bytes": fwd["algorithmic_bytes"],
-                                  "source": "profiles/roofline_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, separate "
-                                            "passes; L2->fabric requests, mostly Infinity-Cache hits)"}
+                                  "source": "STATIC: read from profiles/roofline_traffic.json, not measured in this run (rocprofv3 "
+                                            "--pmc FETCH_SIZE/WRITE_SIZE in separate passes, FETCH doubled per MI355X_MICROARCH.md; "
+                                            "L2->fabric requests, mostly Infinity-Cache hits)"}
             except Exception:
                 traffic, traffic_detail = None, None
         train = dict(
@@ -232,6 +266,30 @@ def main():
                                    for k, v in by_tag.items() if v[1] > 0}),
             e2e_frac_mfma_peak=None if tiny else round(value / world * FLOPS_TRAIN_SAMPLE / (PEAK_BF16_TFLOPS * 1e12), 4),
         )
+
+    # ------------------------------------------------------------------ the other BASELINE.json configs (N = 1 only, short)
+    configs = None
+    if world == 1 and not tiny and not a.no_configs:
+        configs = {}
+        try:
+            del batch, opt, ddp
+        except NameError:
+            pass
+        try:
+            from tools import bench_configs as BC
+            res = []
+            BC.config2(None, BC.default_args(), model=model, sink=res)   # image-comprehension prefill + greedy decode (config 2)
+            configs["config2"] = res
+        except Exception as ex:
+            configs["config2"] = {"error": repr(ex)}
+        try:
+            del model, head
+            torch.cuda.empty_cache()
+            res = []
+            BC.config5(None, BC.default_args(), sink=res)                # DreamLLM-SDXL stage-I step + SDXL denoise (config 5)
+            configs["config5"] = res
+        except Exception as ex:
+            configs["config5"] = {"error": repr(ex)}
 
     if rank == 0:
         line = {
@@ -250,6 +308,7 @@ def main():
             "roofline": train.get("roofline"),
             "e2e_frac_mfma_peak": train.get("e2e_frac_mfma_peak"),
             "denoise": denoise,
+            "configs": configs,
         }
         if world == 1 and not a.no_cpu_baseline:
             try:

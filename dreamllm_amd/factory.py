@@ -17,6 +17,15 @@ VICUNA_7B = dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=32
                  max_position_embeddings=2048, rms_norm_eps=1e-6)
 TINY = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=512,
             rms_norm_eps=1e-6)
+# miniature plugin architectures for smoke() / `bench.py --model tiny` (every block type of the full-size graphs)
+TINY_CLIP = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, image_size=56)
+TINY_DIFFUSION = dict(
+    unet=dict(sample_size=16, in_channels=4, out_channels=4, block_out_channels=(64, 128, 128, 128), layers_per_block=1,
+              down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"),
+              up_block_types=("UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"),
+              attention_head_dim=(1, 2, 2, 2), transformer_layers_per_block=1, cross_attention_dim=64, norm_num_groups=32,
+              norm_eps=1e-5, flip_sin_to_cos=True, freq_shift=0, addition_embed_type=None),
+    vae=dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1))
 
 
 @contextlib.contextmanager

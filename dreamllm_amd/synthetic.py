@@ -51,6 +51,9 @@ def make_interleaved_batch(batch_size=16, seq_len=2048, images_per_sample=2, n_d
         input_ids=ids.to(device), attention_mask=mask.to(device), labels=labels.to(device),
         dream_index=(dpos[:, None] + 1 + torch.arange(n_dream)[None]).reshape(-1).to(device),
         image_index=(ipos[:, None] + 1 + torch.arange(n_patch)[None]).reshape(-1).to(device),
+        # valid tokens per (right-padded) row, as data.DataCollatorForDreamLLMDataset emits them: the step then needs no
+        # device->host sync to validate / reduce the mask
+        seqlens=mask.sum(-1).to(torch.int32).to(device),
     )
     if with_pixels:
         n_img = batch_size * K

@@ -34,7 +34,10 @@ def timed(fn, iters, warmup):
     return (time.perf_counter() - t0) / iters
 
 
-def emit(out, **kw):
+def emit(out, sink=None, **kw):
+    if sink is not None:  # called from bench.py: collect instead of printing (bench.py prints ONE JSON line)
+        sink.append(kw)
+        return
     line = json.dumps(kw)
     print(line, flush=True)
     if out:
@@ -42,10 +45,11 @@ def emit(out, **kw):
             f.write(line + "\n")
 
 
-def config2(out, a):
+def config2(out, a, model=None, sink=None):
     from dreamllm_amd.factory import build_dreamllm
     from dreamllm_amd.synthetic import make_interleaved_batch
-    model = build_dreamllm(None, device="cuda", dtype=BF, with_sd=False).eval()
+    own = model is None
+    model = (build_dreamllm(None, device="cuda", dtype=BF, with_sd=False) if own else model).eval()
     # one comprehension image per prompt: [bos] text <im_start> 256 patches <im_end> text
     S = a.prompt_len
     b = make_interleaved_batch(batch_size=a.prefill_batch, seq_len=S + 66, images_per_sample=1, device="cuda", dtype=BF)
@@ -55,7 +59,7 @@ def config2(out, a):
                                 return_dict=True), a.iters, 1)
     ntok = ids.numel()
     flops = 13.75e9 * ntok + 0.162e12 * img.shape[0]
-    emit(out, config=2, metric="image-comprehension prefill tokens/s", value=round(ntok / t, 1), unit="tokens/s",
+    emit(out, sink, config=2, metric="image-comprehension prefill tokens/s", value=round(ntok / t, 1), unit="tokens/s",
          batch=a.prefill_batch, seq_len=ids.shape[1], images=img.shape[0], ms=round(t * 1e3, 2),
          frac_mfma_peak=round(flops / t / 1e12 / PEAK_TF, 4), dtype="bf16", data="synthetic")
     # greedy decode, batch 1, KV cache: token steps on the decode kernels, one hipGraph replay per token
@@ -73,12 +77,15 @@ def config2(out, a):
     per_tok = (time.perf_counter() - t0) / new
     wbytes = sum(p.numel() for n, p in model.named_parameters()
                  if n.startswith("model.layers") or n.startswith("lm_head") or n == "model.norm.weight") * 2
-    emit(out, config=2, metric="greedy decode tokens/s (batch 1, KV cache)", value=round(1.0 / per_tok, 1), unit="tokens/s",
+    emit(out, sink, config=2, metric="greedy decode tokens/s (batch 1, KV cache)", value=round(1.0 / per_tok, 1), unit="tokens/s",
          ms_per_token=round(per_tok * 1e3, 3), new_tokens=new, context=int(ids1.shape[1]),
          roofline=dict(bound="hbm", achieved=round(wbytes / per_tok / 1e9, 1), peak=PEAK_GBS, unit="GB/s",
                        frac=round(wbytes / per_tok / 1e9 / PEAK_GBS, 4), algorithmic_bytes_per_token=wbytes),
          dtype="bf16", data="synthetic")
-    del model
+    model._decode_session = None
+    del sess
+    if own:
+        del model
     torch.cuda.empty_cache()
 
 
@@ -108,7 +115,7 @@ def config3(out, a):
     torch.cuda.empty_cache()
 
 
-def config5(out, a):
+def config5(out, a, sink=None):
     from dreamllm_amd.factory import build_dreamllm_sdxl
     from dreamllm_amd.optim import HipAdamW
     from dreamllm_amd.schedulers import DDIMScheduler
@@ -129,7 +136,7 @@ def config5(out, a):
     lat = a.sdxl_px // 8
     unet_fwd = 6.89e12 * (lat / 128.0) ** 2  # SDXL UNet fwd @128x128, 196 ctx tokens
     flops = B * (2 * unet_fwd + 2 * 13.75e9 * S)
-    emit(out, config=5, metric="DreamLLM-SDXL stage-I train samples/s (frozen LLM fwd+dgrad, SDXL UNet fwd+dgrad)",
+    emit(out, sink, config=5, metric="DreamLLM-SDXL stage-I train samples/s (frozen LLM fwd+dgrad, SDXL UNet fwd+dgrad)",
          value=round(B / t, 3), unit="samples/s", batch=B, seq_len=S, image_px=a.sdxl_px, ms_per_step=round(t * 1e3, 1),
          trainable_params=sum(p.numel() for p in params), frac_mfma_peak=round(flops / t / 1e12 / PEAK_TF, 4), dtype="bf16",
          data="synthetic", n_gpus=1)
@@ -147,12 +154,12 @@ def config5(out, a):
                       prompt_embeds=pe, negative_prompt_embeds=ne, output_type="latent", scheduler=sched)
 
     t = timed(run, 1, 1)
-    emit(out, config=5, metric="SDXL denoise steps/s (DDIM eta=0, CFG 7.5, B_img=1)", value=round(steps / t, 2), unit="steps/s",
+    emit(out, sink, config=5, metric="SDXL denoise steps/s (DDIM eta=0, CFG 7.5, B_img=1)", value=round(steps / t, 2), unit="steps/s",
          image_px=a.sdxl_px, ms_per_step=round(t / steps * 1e3, 2), frac_mfma_peak=round(2 * unet_fwd * steps / t / 1e12 / PEAK_TF, 4),
          dtype="bf16", data="synthetic")
 
 
-def main():
+def _parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="2,3,5")
     ap.add_argument("--out", default="")
@@ -164,7 +171,15 @@ def main():
     ap.add_argument("--sdxl-seq-len", type=int, default=256)
     ap.add_argument("--sdxl-px", type=int, default=1024)
     ap.add_argument("--sdxl-denoise-steps", type=int, default=20)
-    a = ap.parse_args()
+    return ap
+
+
+def default_args():
+    return _parser().parse_args([])
+
+
+def main():
+    a = _parser().parse_args()
     if a.out and os.path.exists(a.out):
         os.remove(a.out)
     sel = set(a.only.split(","))
