@@ -189,7 +189,7 @@ def main():
         params = [p for p in model.parameters() if p.requires_grad]
         if a.sharded_grad and world > 1:
             ddp = model
-            opt = D.ShardedGradAdamW(params, lr=2e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
+            opt = D.ShardedGradAdamW(params, lr=2e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, overlap=True)
         else:
             ddp = D.wrap_ddp(model)
             opt = HipAdamW(params, lr=2e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)

@@ -123,8 +123,13 @@ class ShardedGradAdamW:
     tests inject a torch restatement (the product path has no CPU fallback)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None, bucket_mb=512,
-                 state_dtype=None, update_fn=None, sumsq_fn=None, process_group=None):
-        """`params`: an iterable of parameters, or torch-style param groups `[{"params": [...], "weight_decay": 0.0}, ...]`
+                 state_dtype=None, update_fn=None, sumsq_fn=None, process_group=None, overlap=False):
+        """`overlap=True`: a bucket's reduce-scatter is issued (async, on the communication stream) from a
+        post-accumulate-grad hook the moment the LAST gradient of the bucket has been written by the backward -- buckets are
+        filled in reverse layer order, so the collectives of the late layers run under the backward of the early ones, as DDP's
+        bucket hooks do.  Requires one `step()` per backward (no gradient accumulation across backwards).
+
+        `params`: an iterable of parameters, or torch-style param groups `[{"params": [...], "weight_decay": 0.0}, ...]`
         (the reference trainer excludes biases and `ALL_LAYERNORM_LAYERS` weights from decay, omni/train/trainer.py:388-411):
         a bucket never mixes decay values.  Invariant shared with DDP's `static_graph`: every trainable parameter receives
         a gradient every step (the gradients live in flat buffers, so "no gradient" cannot be told from a zero gradient)."""
@@ -194,6 +199,31 @@ class ShardedGradAdamW:
             self.shard_v.append(torch.zeros(shard, dtype=sd, device=fp.device))
             self.layout.append((n, padded, shard))
 
+        self.overlap = bool(overlap) and self.world > 1
+        self._pending = [None] * len(self.buckets)   # (work handle, output shard) of a reduce-scatter already in flight
+        self._left = [len(b) for b in self.buckets]
+        if self.overlap:
+            for bi, bucket in enumerate(self.buckets):
+                for p in bucket:
+                    p.register_post_accumulate_grad_hook(self._make_hook(bi))
+
+    def _make_hook(self, bi):
+        def hook(_param):
+            self._left[bi] -= 1
+            if self._left[bi] == 0:
+                self._pending[bi] = self._launch_reduce(bi, async_op=True)
+        return hook
+
+    def _launch_reduce(self, bi, async_op=False):
+        """reduce-scatter(sum) of bucket bi's flat gradient -> (work or None, this rank's shard)."""
+        fg, (n, padded, shard) = self.flat_g[bi], self.layout[bi]
+        out = torch.empty(shard, dtype=fg.dtype, device=fg.device)
+        if self.tensor_collectives:
+            work = dist.reduce_scatter_tensor(out, fg, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+        else:
+            work = dist.all_reduce(fg, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
+        return (work if async_op else None), out
+
     # ---- optimizer-like surface ------------------------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = False):
         """Gradients live in the flat buffers: they are zeroed in place (set_to_none would detach the views)."""
@@ -226,18 +256,19 @@ class ShardedGradAdamW:
         self._step += 1
         W, r = self.world, self.rank
         gshards = []
-        for fg, (n, padded, shard) in zip(self.flat_g, self.layout):
+        for bi, (fg, (n, padded, shard)) in enumerate(zip(self.flat_g, self.layout)):
             if W > 1:
-                out = torch.empty(shard, dtype=fg.dtype, device=fg.device)
-                if self.tensor_collectives:
-                    dist.reduce_scatter_tensor(out, fg, op=dist.ReduceOp.SUM, group=self.pg)
-                else:
-                    dist.all_reduce(fg, op=dist.ReduceOp.SUM, group=self.pg)
+                pend, self._pending[bi] = self._pending[bi], None
+                work, out = pend if pend is not None else self._launch_reduce(bi)
+                if work is not None:
+                    work.wait()  # orders the compute stream behind the collective; no host block on RCCL
+                if not self.tensor_collectives:
                     out.copy_(fg[r * shard:(r + 1) * shard])
                 out.div_(W)  # mean, as DDP (ReduceOp.AVG is not available on every backend)
             else:
                 out = fg[:shard]
             gshards.append(out)
+        self._left = [len(b) for b in self.buckets]
         coef = None
         if self.max_grad_norm is not None:
             sq = torch.stack([self.sumsq_fn(g).reshape(()) for g in gshards]).sum()

@@ -20,20 +20,23 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, mode="ddp"):
-    os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, q, mode="ddp", backend="gloo"):
+    local = rank if backend == "nccl" else 0  # RCCL: one device per rank; gloo: both ranks share the box's single GPU
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     from dreamllm_amd import distributed as D
-    from dreamllm_amd.factory import TINY, build_dreamllm
+    from dreamllm_amd.factory import TINY, TINY_CLIP, TINY_DIFFUSION, build_dreamllm
     from dreamllm_amd.optim import HipAdamW
     from dreamllm_amd.synthetic import make_interleaved_batch
-    from oracle import unet_ref
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda", 0)
-    model = build_dreamllm(TINY, device=dev, seed=0,
-                           clip=dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=56),
-                           diffusion=dict(unet=unet_ref.tiny_config(64), vae=dict(block_out_channels=(32, 64, 64, 64), layers_per_block=1)),
+    torch.cuda.set_device(local)
+    if backend == "nccl":
+        assert D.init_distributed("nccl") == world and dist.get_backend() == "nccl"   # the path bench.py takes for N > 1
+        assert D.max_over_ranks(1.0 + rank) == float(world)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", local)
+    model = build_dreamllm(TINY, device=dev, seed=0, clip=dict(TINY_CLIP, num_hidden_layers=2), diffusion=TINY_DIFFUSION,
                            num_dream_queries=8).train()
     if mode == "ddp":
         ddp = D.wrap_ddp(model, bucket_cap_mb=1)
@@ -41,7 +44,9 @@ def _worker(rank, world, port, q, mode="ddp"):
         opt = HipAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=1.0)
     else:  # sharded-gradient mode: plain replica forward/backward, reduce-scatter + sharded AdamW + all-gather in the step
         ddp = model
-        opt = D.ShardedGradAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=1.0, bucket_mb=1)
+        opt = D.ShardedGradAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=1.0, bucket_mb=1,
+                                 overlap=(mode == "sharded_overlap"))
+        assert opt.tensor_collectives == (backend == "nccl")
     batch = make_interleaved_batch(2, 256, 1, n_dream=8, n_patch=16, seed=100 + rank, device=dev, image_size=56, dm_size=128)
     torch.manual_seed(5)  # same diffusion noise / timesteps on both ranks is not required; losses differ per rank by data
     losses, gsig = [], None
@@ -82,11 +87,11 @@ def test_ddp_two_ranks_tiny_model():
     assert l0 != l1  # different data shards
 
 
-def _run(mode):
+def _run(mode, backend="gloo"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
@@ -109,3 +114,20 @@ def test_sharded_grad_mode_matches_ddp():
     n_train = a.numel()
     assert sh[0][6] <= 2 * 2 * (n_train // 2 + 64)    # two bf16 moments over half the parameters (+ padding per bucket)
     assert abs(sh[0][4][0] - dd[0][4][0]) < 1e-3 * abs(dd[0][4][0])  # first-step loss identical up to rounding
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank: runs on multi-GPU nodes only")
+def test_rccl_two_ranks_ddp_and_sharded_grad():
+    """The multi-GPU path of bench.py executed on RCCL (backend "nccl") with 2 ranks on 2 devices: `init_distributed` ->
+    `wrap_ddp` -> 2 steps, and `ShardedGradAdamW` (reduce_scatter_tensor / all_gather_into_tensor, with and without the
+    backward overlap) -> 2 steps; replicas identical, the three modes agree with each other."""
+    dd = _run("ddp", "nccl")
+    sh = _run("sharded", "nccl")
+    so = _run("sharded_overlap", "nccl")
+    for res in (dd, sh, so):
+        assert res[0][1] == [] and res[1][1] == []
+        assert res[0][5] == res[1][5]                 # replicas identical after 2 steps
+        assert res[0][4] != res[1][4]                 # different data shards
+    a, b, c = (torch.tensor(r[0][5]) for r in (dd, sh, so))
+    assert ((b - a).norm() / a.norm()) < 2e-3 and ((c - a).norm() / a.norm()) < 2e-3
+    assert torch.equal(b, c)                          # overlap changes when the collectives run, not what they compute

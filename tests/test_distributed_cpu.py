@@ -88,14 +88,14 @@ def _sumsq(g):
     return (g.float() ** 2).sum()
 
 
-def _sharded_worker(rank, world, port, q):
+def _sharded_worker(rank, world, port, q, overlap=False):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from dreamllm_amd import distributed as D
     D.init_distributed("gloo")
     torch.manual_seed(0)
     model = torch.nn.Sequential(torch.nn.Linear(8, 13), torch.nn.Tanh(), torch.nn.Linear(13, 3))  # odd sizes: padding path
     opt = D.ShardedGradAdamW(model.parameters(), lr=1e-2, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.1, max_grad_norm=0.5,
-                             bucket_mb=1, update_fn=_torch_adamw, sumsq_fn=_sumsq)
+                             bucket_mb=1, update_fn=_torch_adamw, sumsq_fn=_sumsq, overlap=overlap)
     data = torch.arange(80, dtype=torch.float32).view(10, 8) / 80.0
     x = data[list(D.shard_for_rank(10))]
     norms = []
@@ -109,13 +109,18 @@ def _sharded_worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
-def test_sharded_grad_adamw_matches_single_process_adamw():
-    """2 ranks, gloo: reduce-scatter(mean) -> global-norm clip -> AdamW on the local slice -> all-gather reproduces a
+import pytest
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_sharded_grad_adamw_matches_single_process_adamw(overlap):
+    """(overlap=True: the reduction of a bucket is launched from the post-accumulate-grad hook of its last gradient.)
+    2 ranks, gloo: reduce-scatter(mean) -> global-norm clip -> AdamW on the local slice -> all-gather reproduces a
     single-process AdamW step on the mean gradient; both ranks end with identical parameters; moments are half-size."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
