@@ -619,8 +619,10 @@ def test_lm_head_ce_fused_matches_unfused_and_torch(V):
     assert abs(res[True][0].item() - ref.item()) < 1e-4 * abs(ref.item())       # fp32 logits, fp32 CE
     assert torch.equal(res[True][0], res[False][0])                               # same kernels, same row order
     assert rel_l2(res[True][1], hr.grad) < 8e-3 and rel_l2(res[True][2], wr.grad) < 8e-3
-    assert rel_l2(res[True][1], res[False][1]) < 4e-3                             # bf16 roundings at different points
-    assert rel_l2(res[True][2], res[False][2]) < 4e-3
+    # the fused unit rounds its gradients to bf16 BEFORE the upstream scalar (0.37 here; exactly 1.0 in the stage-II loss mix,
+    # where the product is exact) is applied, the unfused one folds it in before rounding: two roundings vs one
+    assert rel_l2(res[True][1], res[False][1]) < 7e-3
+    assert rel_l2(res[True][2], res[False][2]) < 7e-3
 
 
 @pytest.mark.parametrize("N,Sq,Sk,C", [(2, 256, 256, 64), (1, 1024, 1024, 512), (1, 100, 72, 128)])

@@ -382,10 +382,12 @@ def test_collator_indices_match_the_model_path(golden):
         exs.append(dict(input_ids=ids[b, :n], attention_mask=am[b, :n], labels=g["labels"][b, :n],
                         images=g["images"][ic:ic + ni] if ni else None, images_dm=g["images_dm"][dc:dc + nd] if nd else None))
         ic, dc = ic + ni, dc + nd
-    col = DataCollatorForDreamLLMDataset.from_model(SimpleNamespace(pad_token_id=int(ids[1, -1])), lm)
+    col = DataCollatorForDreamLLMDataset.from_model(SimpleNamespace(pad_token_id=150), lm)
     assert (col.n_dream, col.n_patch) == (4, 6)
     batch = col(exs)
-    assert torch.equal(batch["input_ids"], ids) and torch.equal(batch["labels"], g["labels"])
+    valid = am.bool()  # the fixture's pad positions hold arbitrary tokens; the collator writes pad_token_id there
+    assert torch.equal(batch["input_ids"][valid], ids[valid]) and torch.equal(batch["labels"], g["labels"])
+    assert torch.equal(batch["attention_mask"], am)
     dev = lambda v: v.to(DEV) if torch.is_tensor(v) and not v.is_floating_point() else (v.to(BF).to(DEV) if torch.is_tensor(v) else v)
     full = {k: dev(v) for k, v in batch.items()}
     a = lm(**full, return_dict=True)
