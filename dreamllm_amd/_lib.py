@@ -40,7 +40,7 @@ SIGNATURES = {
     "dllm_attn_bwd": [c_void_p] * 12 + [c_int] * 6 + [c_i64] * 15 + [c_float, c_int, c_void_p],
     "dllm_rope": [c_void_p] * 4 + [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void_p],
     "dllm_glu_fwd": [c_void_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_i64, c_int, c_void_p],
-    "dllm_glu_bwd": [c_void_p] * 5 + [c_i64, c_int] + [c_i64] * 5 + [c_int, c_void_p],
+    "dllm_glu_bwd": [c_void_p] * 6 + [c_i64, c_int] + [c_i64] * 6 + [c_int, c_void_p],
     "dllm_gather_rows": [c_void_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_void_p],
     "dllm_scatter_rows": [c_void_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_void_p],
     "dllm_segment_sum_rows": [c_void_p] * 5 + [c_i64, c_int, c_i64, c_i64, c_void_p],

@@ -63,14 +63,14 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const bf16* __restrict__ a
 template <int MODE>
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ a,
                                                       const bf16* __restrict__ b, bf16* __restrict__ da, bf16* __restrict__ db,
-                                                      int64_t M, int F, int64_t ldd, int64_t lda, int64_t ldb, int64_t ldda,
-                                                      int64_t lddb) {
+                                                      bf16* __restrict__ act_out, int64_t M, int F, int64_t ldd, int64_t lda,
+                                                      int64_t ldb, int64_t ldda, int64_t lddb, int64_t ldact) {
     const int vpr = F >> 3;
     for (int64_t r = blockIdx.x; r < M; r += gridDim.x)
     for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
         const int c = v * 8;
         const bf16x8 dv = ld_bf16x8(dout + r * ldd + c), av = ld_bf16x8(a + r * lda + c), bv = ld_bf16x8(b + r * ldb + c);
-        bf16x8 oa, ob;
+        bf16x8 oa, ob, oc;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float d = (float)dv[e], x = (float)av[e], y = (float)bv[e];
@@ -85,9 +85,11 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const bf16* __restrict__ d
             }
             oa[e] = (bf16)(d * y * dact);
             ob[e] = (bf16)(d * act);
+            oc[e] = (bf16)(act * y);  // the forward product, recomputed in the same pass for the down-projection's weight gradient
         }
         st_bf16x8(da + r * ldda + c, oa);
         st_bf16x8(db + r * lddb + c, ob);
+        if (act_out != nullptr) st_bf16x8(act_out + r * ldact + c, oc);
     }
 }
 
@@ -504,18 +506,19 @@ int dllm_glu_fwd(const void* a, const void* b, void* out, int64_t M, int F, int6
                            (bf16*)out, M, F, lda, ldb, ldo);
     return dllm_check_launch();
 }
-int dllm_glu_bwd(const void* dout, const void* a, const void* b, void* da, void* db, int64_t M, int F, int64_t ldd, int64_t lda,
-                 int64_t ldb, int64_t ldda, int64_t lddb, int mode, void* stream) {
+int dllm_glu_bwd(const void* dout, const void* a, const void* b, void* da, void* db, void* act_out, int64_t M, int F, int64_t ldd,
+                 int64_t lda, int64_t ldb, int64_t ldda, int64_t lddb, int64_t ldact, int mode, void* stream) {
     if (M < 0 || F <= 0 || (F & 7) || ((ldd | lda | ldb | ldda | lddb) & 7)) return DLLM_ERR_SHAPE;
+    if (act_out != nullptr && (ldact & 7)) return DLLM_ERR_SHAPE;
     if (M == 0) return DLLM_OK;
     const unsigned g = (unsigned)(M < (1 << 20) ? M : (1 << 20));
     const int vpr = F / 8, nthr = vpr >= 256 ? 256 : ((vpr + 63) / 64) * 64;
     if (mode == 0)
         hipLaunchKernelGGL(glu_bwd_kernel<0>, dim3(g), dim3(nthr), 0, (hipStream_t)stream, (const bf16*)dout, (const bf16*)a,
-                           (const bf16*)b, (bf16*)da, (bf16*)db, M, F, ldd, lda, ldb, ldda, lddb);
+                           (const bf16*)b, (bf16*)da, (bf16*)db, (bf16*)act_out, M, F, ldd, lda, ldb, ldda, lddb, ldact);
     else
         hipLaunchKernelGGL(glu_bwd_kernel<1>, dim3(g), dim3(nthr), 0, (hipStream_t)stream, (const bf16*)dout, (const bf16*)a,
-                           (const bf16*)b, (bf16*)da, (bf16*)db, M, F, ldd, lda, ldb, ldda, lddb);
+                           (const bf16*)b, (bf16*)da, (bf16*)db, (bf16*)act_out, M, F, ldd, lda, ldb, ldda, lddb, ldact);
     return dllm_check_launch();
 }
 

@@ -179,6 +179,9 @@ class ShardedGradAdamW:
             self.buckets.append(cur)
             self.bucket_wd.append(cur_wd)
         self.flat_p, self.flat_g, self.shard_m, self.shard_v, self.layout = [], [], [], [], []
+        # inside a bucket the parameters sit in REGISTRATION order: weights packed for single-GEMM use (q|k|v, gate|up:
+        # modeling_dreamllm.pack_linear_weights) stay adjacent, in order, after they move into the flat buffer
+        self.buckets = [b[::-1] for b in self.buckets]
         for bucket in self.buckets:
             n = sum(p.numel() for p in bucket)
             padded = (n + self.world - 1) // self.world * self.world
@@ -189,6 +192,7 @@ class ShardedGradAdamW:
                 k = p.numel()
                 fp[off:off + k].copy_(p.data.reshape(-1))
                 p.data = fp[off:off + k].view(p.shape)   # the parameter now lives in the flat buffer
+                p._dllm_flat_owned = True                # nobody else may re-point it (DreamLLMDecoderLayer.pack_weights)
                 p.grad = fg[off:off + k].view(p.shape)   # autograd accumulates into the flat gradient buffer
                 off += k
             shard = padded // self.world

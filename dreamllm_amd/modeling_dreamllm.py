@@ -107,91 +107,177 @@ class RotaryEmbedding(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------- fused decoder layer
+def _packed_view(*ws):
+    """[sum(out_i), in] view over weights that are adjacent slices of one storage, in this order (see `pack_linear_weights`);
+    None when they are not -- the caller then runs one GEMM per weight."""
+    w0 = ws[0]
+    if any(w.dtype != w0.dtype or w.device != w0.device or w.dim() != 2 or w.shape[1] != w0.shape[1] or not w.is_contiguous()
+           for w in ws):
+        return None
+    es, ptr = w0.element_size(), w0.data_ptr()
+    for w in ws:
+        if w.data_ptr() != ptr:
+            return None
+        ptr += w.numel() * es
+    rows = sum(w.shape[0] for w in ws)
+    room = w0.untyped_storage().nbytes() - w0.storage_offset() * es
+    if room < rows * w0.shape[1] * es:
+        return None
+    return torch.as_strided(w0.detach(), (rows, w0.shape[1]), (w0.shape[1], 1))
+
+
+def pack_linear_weights(*linears):
+    """Re-point the weights of `linears` (same in_features) at consecutive row blocks of ONE buffer, so that they can be applied
+    as a single GEMM on the packed [sum(out), in] matrix while every `nn.Parameter` keeps its identity, shape and state_dict key
+    (`q_proj.weight`, ...: modeling_dreamllm.py:273-275,219-220).  In-place updates (optimizers, `load_state_dict`, `copy_`)
+    keep the packing; `module.to(dtype/device)` re-allocates the parameters and drops it (call again afterwards)."""
+    ws = [l.weight for l in linears]
+    if _packed_view(*[w.data for w in ws]) is not None:
+        return
+    buf = torch.cat([w.data for w in ws], dim=0).contiguous()
+    r = 0
+    for w in ws:
+        n = w.shape[0]
+        w.data = buf[r:r + n]
+        r += n
+
+
 class _DecoderLayerFn(torch.autograd.Function):
-    """DreamLLMDecoderLayer.forward (modeling_dreamllm.py:622-640) with a hand-written backward."""
+    """DreamLLMDecoderLayer.forward (modeling_dreamllm.py:622-640) with a hand-written backward.
+
+    q/k/v and gate/up run as ONE GEMM each when their weights are packed (`pack_linear_weights`): forward y = h [Wq;Wk;Wv]^T
+    straight into a packed [T, (H + 2 Hkv) D] buffer whose q/k/v column blocks are the strided views attention and RoPE take
+    (one RoPE launch over the q and k heads); backward dh = [dq|dk|dv] [Wq;Wk;Wv] as one GEMM over K = 3H (no accumulating
+    passes over dh), and one weight-gradient GEMM whose row blocks are the three gradients.  Same for [gate; up].  With
+    unpacked weights the layer falls back to one GEMM per projection (identical results up to the GEMM's own rounding)."""
 
     @staticmethod
     def forward(ctx, x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, n_heads, n_kv, eps, want_kv):
         B, S, Hd = x.shape
         hd = Hd // n_heads
+        T = B * S
+        nq, nkv = n_heads * hd, n_kv * hd
         h, _, rstd1 = ops.rmsnorm_fwd(x, w_in, eps)
-        q = ops.linear_fwd(h, wq).view(B, S, n_heads, hd)
-        k = ops.linear_fwd(h, wk).view(B, S, n_kv, hd)
-        v = ops.linear_fwd(h, wv).view(B, S, n_kv, hd)
+        wqkv = _packed_view(wq, wk, wv)
+        if wqkv is not None:
+            qkv = ops.linear_fwd(h, wqkv).view(B, S, nq + 2 * nkv)
+        else:
+            qkv = torch.empty(B, S, nq + 2 * nkv, dtype=x.dtype, device=x.device)
+            h2d, o2d = h.view(T, Hd), qkv.view(T, -1)
+            ops.gemm(h2d, wq, T, nq, Hd, Hd, Hd, 0, 0, out=o2d[:, :nq])
+            ops.gemm(h2d, wk, T, nkv, Hd, Hd, Hd, 0, 0, out=o2d[:, nq:nq + nkv])
+            ops.gemm(h2d, wv, T, nkv, Hd, Hd, Hd, 0, 0, out=o2d[:, nq + nkv:])
         del h
-        ops.rope_(q, cos, sin, pos)
-        ops.rope_(k, cos, sin, pos)
+        qk = qkv[:, :, : nq + nkv].unflatten(-1, (n_heads + n_kv, hd))   # q heads then k heads: one RoPE launch
+        ops.rope_(qk, cos, sin, pos)
+        q = qkv[:, :, :nq].unflatten(-1, (n_heads, hd))
+        k = qkv[:, :, nq:nq + nkv].unflatten(-1, (n_kv, hd))
+        v = qkv[:, :, nq + nkv:].unflatten(-1, (n_kv, hd))
         need_bwd = any(ctx.needs_input_grad[:10])
         o, lse = ops.attn_fwd(q, k, v, True, 1.0 / math.sqrt(hd), seqlens, need_lse=need_bwd, seqstart=seqstart)
         x2 = ops.linear_fwd(o.view(B, S, Hd), wo, residual=x)
         h2, _, rstd2 = ops.rmsnorm_fwd(x2, w_post, eps)
-        g = ops.linear_fwd(h2, wg)
-        u = ops.linear_fwd(h2, wu)
+        F_ = wg.shape[0]
+        wgu = _packed_view(wg, wu)
+        if wgu is not None:
+            gu = ops.linear_fwd(h2, wgu).view(T, 2 * F_)
+        else:
+            gu = torch.empty(T, 2 * F_, dtype=x.dtype, device=x.device)
+            h22 = h2.view(T, Hd)
+            ops.gemm(h22, wg, T, F_, Hd, Hd, Hd, 0, 0, out=gu[:, :F_])
+            ops.gemm(h22, wu, T, F_, Hd, Hd, Hd, 0, 0, out=gu[:, F_:])
         del h2
-        act = ops.glu_fwd(g, u, 0)
-        y = ops.linear_fwd(act, wd, residual=x2)
+        act = ops.glu_fwd(gu[:, :F_], gu[:, F_:], 0)
+        y = ops.linear_fwd(act.view(B, S, F_), wd, residual=x2)
         if need_bwd:
-            ctx.save_for_backward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, q, k, v, o,
-                                  lse, x2, rstd2, g, u)
+            ctx.save_for_backward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, qkv, o, lse,
+                                  x2, rstd2, gu)
             ctx.cfg = (n_heads, n_kv, eps)
         if want_kv:
+            k, v = k.contiguous(), v.contiguous()  # the cache must not pin the packed q/k/v buffer
             ctx.mark_non_differentiable(k, v)
             return y, k, v
         return y, None, None
 
     @staticmethod
     def backward(ctx, dy, _dk, _dv):
-        (x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, q, k, v, o, lse, x2, rstd2, g,
-         u) = ctx.saved_tensors
+        (x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, qkv, o, lse, x2, rstd2,
+         gu) = ctx.saved_tensors
         n_heads, n_kv, eps = ctx.cfg
         B, S, Hd = x.shape
         hd = Hd // n_heads
+        T = B * S
+        nq, nkv = n_heads * hd, n_kv * hd
+        F_ = wg.shape[0]
         need = ctx.needs_input_grad
         dy = dy.contiguous()
         # ---- MLP
         d_act = ops.linear_dgrad(dy, wd)
+        g, u = gu[:, :F_], gu[:, F_:]
+        dgu = torch.empty_like(gu)
+        act = torch.empty(T, F_, dtype=x.dtype, device=x.device) if need[9] else None
+        ops.glu_bwd(d_act, g, u, 0, da=dgu[:, :F_], db=dgu[:, F_:], act_out=act)  # dg, du AND the recomputed product in one pass
+        del d_act
         dwd = None
         if need[9]:
-            act = ops.glu_fwd(g, u, 0)  # recomputed, not stored
             dwd = ops.linear_wgrad(dy, act)
             del act
-        dg, du = ops.glu_bwd(d_act, g, u, 0)
-        del d_act
+        wgu = _packed_view(wg, wu)
         dwg = dwu = None
         if need[7] or need[8]:
             h2, _, _ = ops.rmsnorm_fwd(x2, w_post, eps)  # recomputed
-            if need[7]:
-                dwg = ops.linear_wgrad(dg, h2)
-            if need[8]:
-                dwu = ops.linear_wgrad(du, h2)
+            if wgu is not None and need[7] and need[8]:
+                dwgu = ops.linear_wgrad(dgu, h2)
+                dwg, dwu = dwgu[:F_], dwgu[F_:]
+            else:
+                if need[7]:
+                    dwg = ops.linear_wgrad(dgu[:, :F_], h2)
+                if need[8]:
+                    dwu = ops.linear_wgrad(dgu[:, F_:], h2)
             del h2
-        T = B * S
-        dh2 = ops.gemm(dg, wg, T, Hd, wg.shape[0], dg.stride(0), Hd, 0, 1)
-        ops.gemm(du, wu, T, Hd, wu.shape[0], du.stride(0), Hd, 0, 1, out=dh2, accumulate=True)
-        del dg, du
+        if wgu is not None:
+            dh2 = ops.gemm(dgu, wgu, T, Hd, 2 * F_, 2 * F_, Hd, 0, 1)
+        else:
+            dh2 = ops.gemm(dgu[:, :F_], wg, T, Hd, F_, 2 * F_, Hd, 0, 1)
+            ops.gemm(dgu[:, F_:], wu, T, Hd, F_, 2 * F_, Hd, 0, 1, out=dh2, accumulate=True)
+        del dgu
         dx2, dw_post = ops.rmsnorm_bwd(dh2, x2, w_post, rstd2, dh_in=dy, need_dw=need[6])
         del dh2
         # ---- attention
         do = ops.linear_dgrad(dx2, wo).view(B, S, n_heads, hd)
         dwo = ops.linear_wgrad(dx2, o.view(B, S, Hd)) if need[5] else None
-        dq, dk, dv = ops.attn_bwd(do, q, k, v, o, lse, True, 1.0 / math.sqrt(hd), seqlens, seqstart=seqstart)
+        q = qkv[:, :, :nq].unflatten(-1, (n_heads, hd))
+        k = qkv[:, :, nq:nq + nkv].unflatten(-1, (n_kv, hd))
+        v = qkv[:, :, nq + nkv:].unflatten(-1, (n_kv, hd))
+        dqkv = torch.empty_like(qkv)
+        dk_, dv_ = dqkv[:, :, nq:nq + nkv].unflatten(-1, (n_kv, hd)), dqkv[:, :, nq + nkv:].unflatten(-1, (n_kv, hd))
+        ops.attn_bwd(do, q, k, v, o, lse, True, 1.0 / math.sqrt(hd), seqlens, dq=dqkv[:, :, :nq].unflatten(-1, (n_heads, hd)),
+                     dk=dk_, dv=dv_, seqstart=seqstart)
         del do
-        ops.rope_(dq, cos, sin, pos, backward=True)
-        ops.rope_(dk, cos, sin, pos, backward=True)
-        dq2, dk2, dv2 = dq.view(T, -1), dk.view(T, -1), dv.view(T, -1)
+        ops.rope_(dqkv[:, :, : nq + nkv].unflatten(-1, (n_heads + n_kv, hd)), cos, sin, pos, backward=True)
+        d2 = dqkv.view(T, nq + 2 * nkv)
+        wqkv = _packed_view(wq, wk, wv)
         dwq = dwk = dwv = None
         if need[2] or need[3] or need[4]:
             h, _, _ = ops.rmsnorm_fwd(x, w_in, eps)  # recomputed
-            if need[2]:
-                dwq = ops.linear_wgrad(dq2, h)
-            if need[3]:
-                dwk = ops.linear_wgrad(dk2, h)
-            if need[4]:
-                dwv = ops.linear_wgrad(dv2, h)
+            if wqkv is not None and need[2] and need[3] and need[4]:
+                dwqkv = ops.linear_wgrad(d2, h)
+                dwq, dwk, dwv = dwqkv[:nq], dwqkv[nq:nq + nkv], dwqkv[nq + nkv:]
+            else:
+                if need[2]:
+                    dwq = ops.linear_wgrad(d2[:, :nq], h)
+                if need[3]:
+                    dwk = ops.linear_wgrad(d2[:, nq:nq + nkv], h)
+                if need[4]:
+                    dwv = ops.linear_wgrad(d2[:, nq + nkv:], h)
             del h
-        dh = ops.gemm(dq2, wq, T, Hd, wq.shape[0], dq2.stride(0), Hd, 0, 1)
-        ops.gemm(dk2, wk, T, Hd, wk.shape[0], dk2.stride(0), Hd, 0, 1, out=dh, accumulate=True)
-        ops.gemm(dv2, wv, T, Hd, wv.shape[0], dv2.stride(0), Hd, 0, 1, out=dh, accumulate=True)
+        ld = nq + 2 * nkv
+        if wqkv is not None:
+            dh = ops.gemm(d2, wqkv, T, Hd, ld, ld, Hd, 0, 1)
+        else:
+            dh = ops.gemm(d2[:, :nq], wq, T, Hd, nq, ld, Hd, 0, 1)
+            ops.gemm(d2[:, nq:nq + nkv], wk, T, Hd, nkv, ld, Hd, 0, 1, out=dh, accumulate=True)
+            ops.gemm(d2[:, nq + nkv:], wv, T, Hd, nkv, ld, Hd, 0, 1, out=dh, accumulate=True)
         dx, dw_in = ops.rmsnorm_bwd(dh, x, w_in, rstd1, dh_in=dx2, need_dw=need[1])
         return (dx.view(x.shape), dw_in, dwq, dwk, dwv, dwo, dw_post, dwg, dwu, dwd) + (None,) * 9
 
@@ -336,12 +422,28 @@ class DreamLLMDecoderLayer(nn.Module):
         self.mlp = DreamLLMMLP(config)
         self.input_layernorm = DreamLLMRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = DreamLLMRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
+        self._pack_tried = False
+
+    def pack_weights(self):
+        """q/k/v and gate/up weights as row blocks of one buffer each => one GEMM per group (`pack_linear_weights`).  Skipped
+        when an optimizer already owns the parameters' storage (`distributed.ShardedGradAdamW` lays its flat buffers out in
+        registration order, which keeps an existing packing intact)."""
+        a, m = self.self_attn, self.mlp
+        ws = [a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, m.gate_proj.weight, m.up_proj.weight]
+        if any(getattr(w, "_dllm_flat_owned", False) for w in ws):
+            return False
+        pack_linear_weights(a.q_proj, a.k_proj, a.v_proj)
+        pack_linear_weights(m.gate_proj, m.up_proj)
+        return True
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
                 use_cache=False, **kwargs):
         if output_attentions:
             raise ValueError("output_attentions is not available on the flash-attention path (modeling_dreamllm.py:934-936)")
         a = self.self_attn
+        if not self._pack_tried and hidden_states.is_cuda and getattr(a.config, "pack_projection_weights", True):
+            self._pack_tried = True  # once: after `.to(device, dtype)` has settled the parameters (0.4 GB of copies per 7B layer)
+            self.pack_weights()
         if past_key_value is None:
             B, S, _ = hidden_states.shape
             cos, sin = a.rotary_emb.tables(S, hidden_states.device)

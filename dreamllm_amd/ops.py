@@ -327,7 +327,8 @@ def glu_fwd(a, b, mode):
     return out.view(*a.shape[:-1], F)
 
 
-def glu_bwd(dout, a, b, mode, da=None, db=None):
+def glu_bwd(dout, a, b, mode, da=None, db=None, act_out=None):
+    """-> (da, db); `act_out` [M, F] (optional) additionally receives the forward product (recomputed in the same pass)."""
     F = a.shape[-1]
     a2, b2 = a.reshape(-1, F), b.reshape(-1, F)
     d2 = dout.reshape(-1, F)
@@ -337,8 +338,8 @@ def glu_bwd(dout, a, b, mode, da=None, db=None):
     if da is None:
         da = torch.empty(M, F, dtype=a.dtype, device=a.device)
         db = torch.empty(M, F, dtype=a.dtype, device=a.device)
-    check("dllm_glu_bwd", _p(d2), _p(a2), _p(b2), _p(da), _p(db), M, F, d2.stride(0), a2.stride(0), b2.stride(0),
-          da.stride(0), db.stride(0), mode, _stream())
+    check("dllm_glu_bwd", _p(d2), _p(a2), _p(b2), _p(da), _p(db), _p(act_out), M, F, d2.stride(0), a2.stride(0), b2.stride(0),
+          da.stride(0), db.stride(0), act_out.stride(0) if act_out is not None else 0, mode, _stream())
     return da, db
 
 

@@ -123,8 +123,10 @@ int dllm_rope(void* x, const float* cos_tab, const float* sin_tab, const int64_t
 /* mode 0: silu(a)*b = DreamLLMMLP act_fn(gate)*up, modeling_dreamllm.py:237;  mode 1: gelu(a)*b = diffusers GEGLU [ext] */
 int dllm_glu_fwd(const void* a, const void* b, void* out, int64_t M, int F, int64_t lda, int64_t ldb, int64_t ldo, int mode,
                  void* stream);
-int dllm_glu_bwd(const void* dout, const void* a, const void* b, void* da, void* db, int64_t M, int F, int64_t ldd, int64_t lda,
-                 int64_t ldb, int64_t ldda, int64_t lddb, int mode, void* stream);
+/* backward; act_out (nullable): the forward product silu(a)*b / a*gelu(b) re-emitted in the same pass (the decoder layer does not
+ * store it: it is the A operand of the down-projection's weight gradient) */
+int dllm_glu_bwd(const void* dout, const void* a, const void* b, void* da, void* db, void* act_out, int64_t M, int F, int64_t ldd,
+                 int64_t lda, int64_t ldb, int64_t ldda, int64_t lddb, int64_t ldact, int mode, void* stream);
 /* out = a + b[i % period]: residual adds outside a GEMM epilogue, CLIP position embedding [ext] */
 int dllm_add_bcast(const void* a, const void* b, void* out, int64_t n, int64_t period, void* stream);
 int dllm_add_rowgroup(const void* a, const void* b, void* out, int64_t groups, int64_t rows_per_group, int C, void* stream);

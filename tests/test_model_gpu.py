@@ -394,3 +394,43 @@ def test_collator_indices_match_the_model_path(golden):
     bare = {k: v for k, v in full.items() if k not in ("seqlens", "dream_index", "image_index")}
     b = lm(**bare, return_dict=True)
     assert torch.equal(a.loss, b.loss) and torch.equal(a.logits, b.logits)
+
+
+@pytest.mark.parametrize("n_kv", [2, 1])
+def test_decoder_layer_packed_weights_match_unpacked(n_kv):
+    """q/k/v and gate/up as ONE GEMM each over packed weights (`pack_linear_weights`: parameters keep their identity and
+    state_dict keys) against one GEMM per projection: forward, input gradient and every weight gradient; GQA included."""
+    from dreamllm_amd.configuration_dreamllm import DreamLLMConfig
+    from dreamllm_amd.modeling_dreamllm import DreamLLMDecoderLayer, _packed_view
+    res = {}
+    for packed in (False, True):
+        cfg = DreamLLMConfig(vocab_size=64, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+                             num_key_value_heads=n_kv, max_position_embeddings=128)
+        cfg.pack_projection_weights = packed
+        torch.manual_seed(3)
+        layer = DreamLLMDecoderLayer(cfg)
+        keys = list(layer.state_dict())
+        layer = layer.to(DEV, BF)
+        torch.manual_seed(4)
+        x = torch.randn(2, 96, 128, device=DEV).to(BF).requires_grad_(True)
+        lens = torch.tensor([96, 50], dtype=torch.int32, device=DEV)
+        y = layer(x, seqlens=lens)[0]
+        y.backward(torch.randn_like(y))
+        a = layer.self_attn
+        assert (_packed_view(a.q_proj.weight, a.k_proj.weight, a.v_proj.weight) is not None) == packed
+        assert list(layer.state_dict()) == keys and layer.self_attn.k_proj.weight.shape == (n_kv * 64, 128)
+        res[packed] = (y.detach(), x.grad, {n: p.grad for n, p in layer.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0])              # same per-element dot products in the forward
+    assert rel_l2(res[True][1], res[False][1]) < 4e-3           # dh: one K = 3H GEMM vs three accumulating ones (extra roundings)
+    for n in res[True][2]:
+        assert rel_l2(res[True][2][n], res[False][2][n]) < 4e-3, n
+
+
+def test_glu_bwd_emits_forward_product():
+    from dreamllm_amd import ops
+    torch.manual_seed(0)
+    g, u, d = (torch.randn(300, 512, device=DEV).to(BF) for _ in range(3))
+    act = torch.empty_like(g)
+    dg, du = ops.glu_bwd(d, g, u, 0, act_out=act)
+    dg2, du2 = ops.glu_bwd(d, g, u, 0)
+    assert torch.equal(act, ops.glu_fwd(g, u, 0)) and torch.equal(dg, dg2) and torch.equal(du, du2)
