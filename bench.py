@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-denoise", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--no-pack", action="store_true", help="A/B knob: one GEMM per projection instead of packed q|k|v and gate|up")
+    ap.add_argument("--unfused-ce", action="store_true", help="A/B knob: lm_head + CE through the full fp32 logits")
     ap.add_argument("--no-configs", action="store_true", help="skip the short config-2 / config-5 legs (N = 1 only)")
     ap.add_argument("--sharded-grad", action="store_true",
                     help="N>1: reduce-scatter + sharded AdamW + all-gather (distributed.ShardedGradAdamW) instead of DDP all-reduce")
@@ -144,6 +146,10 @@ def main():
     else:
         model = build_dreamllm(VICUNA_7B, device=dev)
     head = model.stable_diffusion_head
+    if a.no_pack:
+        model.config.pack_projection_weights = False
+    if a.unfused_ce:
+        model.config.fused_lm_head_ce = False
     result = {}
 
     # ------------------------------------------------------------------ M2: SD-2.1 512 px denoise steps/s (replicas)

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdreamllm_hip.so")
+LIB_PATH = os.environ.get("DREAMLLM_HIP_LIB") or os.path.join(_HERE, "libdreamllm_hip.so")
 
 c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 

@@ -12,14 +12,16 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-BUILD = os.path.join(CSRC, "build")
-LIB = os.path.join(HERE, "libdreamllm_hip.so")
+BENCH = os.environ.get("DLLM_BENCH_MODES") == "1"
+BUILD = os.path.join(CSRC, "build_bench" if BENCH else "build")
+LIB = os.path.join(HERE, "libdreamllm_hip_bench.so" if BENCH else "libdreamllm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
          "-Wno-unused-result", "-Wno-pass-failed"]
-# DLLM_BENCH_MODES=1 python -m dreamllm_amd.build --force : additionally compiles the wrong-result diagnostic GEMM modes used by
-# tools/gemm_ksweep.py (never part of the shipped library; rebuild with --force afterwards)
-if os.environ.get("DLLM_BENCH_MODES") == "1":
+# DLLM_BENCH_MODES=1 python -m dreamllm_amd.build : a SEPARATE library (libdreamllm_hip_bench.so) that additionally contains the
+# wrong-result diagnostic modes used by tools/ (GEMM no-prefetch / no-store, attention ablations); tools select it with
+# DREAMLLM_HIP_LIB=.../libdreamllm_hip_bench.so.  The shipped library never contains them.
+if BENCH:
     FLAGS.append("-DDLLM_BENCH_MODES")
 
 

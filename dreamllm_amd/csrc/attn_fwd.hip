@@ -14,7 +14,10 @@
 
 namespace {
 
-template <int D, bool CAUSAL>
+// ABL (benchmark builds only, -DDLLM_BENCH_MODES): ablation bits that REMOVE one cost each while keeping every value live,
+// to find what the loop is bound by (wrong results by design): 1 no softmax VALU, 2 no PV MFMAs, 4 no QK^T MFMAs,
+// 8 no global loads / LDS stores in the loop (tile 0 is re-used), 16 no O rescale.
+template <int D, bool CAUSAL, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     constexpr int QT = 2;
     constexpr int BQ = 4 * QT * 16;  // 128
@@ -106,11 +109,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 
     for (int j = 0; j < nblk; ++j) {
         const int kv0 = j * BKV;
-        if (j + 1 < nblk) {
+        if (j + 1 < nblk && !(ABL & 8)) {
             sk.gload(kbase, P.k_ss, kv0 + BKV, sk_len, tid);
             sv.gload(vbase, P.k_ss, kv0 + BKV, sk_len, tid);
         }
-        const char* kt_ = smem + (j & 1) * (2 * TILE);
+        const char* kt_ = smem + ((ABL & 8) ? 0 : (j & 1)) * (2 * TILE);
         const char* vt_ = kt_ + TILE;
         const bool wave_active = (wq0 < sq_len) && !(CAUSAL && kv0 > wq0 + QT * 16 - 1 + coff);
         if (wave_active) {
@@ -124,6 +127,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
                     const bf16x8 kf = Img::frag_row(kt_, kt * 16, ds, lane);
+                    if (ABL & 4) {
+                        asm volatile("" ::"v"(kf));
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) s[kt][qt][0] += (float)qf[qt][ds][0];
+                        continue;
+                    }
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
                         s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s[kt][qt], 0, 0, 0);
@@ -133,6 +142,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
             bf16x8 pb[QT][2];
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
+                if (ABL & 1) {  // no softmax: scores go straight to bf16
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            pb[qt][ks][r] = (bf16)s[2 * ks][qt][r];
+                            pb[qt][ks][4 + r] = (bf16)s[2 * ks + 1][qt][r];
+                        }
+                    continue;
+                }
                 const int qidx = wq0 + qt * 16 + t;
                 // running max in the RAW score domain (scale > 0 commutes with max); exp2 argument by one FMA per element
                 float mx = -INFINITY;
@@ -165,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
                     }
                 l_run[qt] = l_run[qt] * alpha + rs;
                 m_run[qt] = m_new;
-                if (!__all(alpha == 1.0f)) {  // wave-uniform: skip the O rescale when no lane's running max moved
+                if (!(ABL & 16) && !__all(alpha == 1.0f)) {  // wave-uniform: skip the O rescale when no lane's running max moved
 #pragma unroll
                     for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
                 }
@@ -182,13 +201,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
                     const bf16x8 va = Img::frag_col(vt_, dt * 16, (2 * ks) * 16, (2 * ks + 1) * 16, lane);
+                    if (ABL & 2) {
+                        asm volatile("" ::"v"(va));
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) oacc[dt][qt][0] += (float)pb[qt][ks][0];
+                        continue;
+                    }
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
                         oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qt][ks], oacc[dt][qt], 0, 0, 0);
                 }
             }
         }
-        if (j + 1 < nblk) {
+        if (j + 1 < nblk && !(ABL & 8)) {
             char* nk = smem + ((j + 1) & 1) * (2 * TILE);
             sk.lstore_row(nk, tid);
             sv.lstore_col(nk + TILE, tid);
@@ -218,13 +243,290 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ 8-wave pipelined forward
+// Same math and LDS images as attn_fwd_kernel, restructured for the long-sequence shapes (LLM prefill / training, UNet 1024+
+// tokens) after an ablation of the 4-wave kernel at B16 x S2048 x H32 x D128 (tools/attn_ablate.py, profiles/r02_attn_ablate.log):
+// softmax VALU 35 % and tile staging 28 % of the time, the MFMAs 10 %, everything serialised inside a wave.
+//   * block = 8 waves x 32 queries = 256 queries: a K/V tile is fetched and written to LDS once per 256 queries (staging
+//     instructions per FLOP halve); full tiles use uniform-base + one per-thread offset addressing.
+//   * software pipeline inside the wave: S(j+1) = K(j+1) Q^T is issued BEFORE the softmax of S(j), so the MFMA pipe works
+//     under the softmax's VALU instructions (K runs one tile ahead of V in LDS; scores are double-buffered in registers).
+//   * softmax diet: row max through v_permlane16/32_swap (no LDS round trip of ds_bpermute), row sums on the matrix pipe
+//     (one extra MFMA with an all-ones A operand per 32 keys instead of 32 VALU adds per lane), v_max3 / cvt_pk by the compiler.
+template <int D>
+__device__ __forceinline__ float group_max4(float x) {  // max over the 4 lanes {t, t+16, t+32, t+48}
+    const uint32_t u = __float_as_uint(x);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const uint32_t v = __float_as_uint(m);
+    auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 template <int D, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
+    constexpr int QT = 2, NW = 8;
+    constexpr int BQ = NW * QT * 16;  // 256
+    constexpr int BKV = 64;
+    constexpr int DS = D / 32, DT = D / 16;
+    constexpr int TILE = BKV * D * 2;
+    using Img = TileImg<D>;
+    using Stage = TileStage<D, BKV, 512>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // K[2] then V[2]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, t = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int qblk = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;  // heavy causal blocks first
+    const int hk = h / (P.H / P.Hkv);
+    const AttnSpan sp = attn_span(P, b);
+    const int sq_len = sp.sq_len, sk_len = sp.sk_len, SqE = sp.SqE;
+    const int q0 = qblk * BQ, wq0 = q0 + wave * (QT * 16);
+    const int coff = sk_len - sq_len;
+
+    bf16* obase = P.o + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh;
+    float* lsebase = P.lse ? P.lse + ((int64_t)b * P.H + h) * P.Sq : nullptr;
+    if (sp.qst > 0) {
+        if (qblk == 0) {
+            zero_head_rows<D, 512>(obase, P.o_ss, sp.qst, tid);
+            if (lsebase)
+                for (int i = tid; i < sp.qst; i += 512) lsebase[i] = 0.f;
+        }
+        obase += (int64_t)sp.qst * P.o_ss;
+        if (lsebase) lsebase += sp.qst;
+    }
+    if (q0 >= sq_len) {  // padded tail: zeros (pad_input semantics, modeling_dreamllm.py:545)
+        for (int i = tid; i < BQ * (D / 8); i += 512) {
+            const int r = q0 + i / (D / 8), c = i % (D / 8);
+            if (r < SqE) st_bf16x8(obase + (int64_t)r * P.o_ss + c * 8, zero_bf16x8());
+        }
+        if (lsebase)
+            for (int i = tid; i < BQ; i += 512)
+                if (q0 + i < SqE) lsebase[q0 + i] = 0.f;
+        return;
+    }
+
+    bf16x8 qf[QT][DS];
+    {
+        const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int qrow = min(wq0 + qt * 16 + t, sq_len - 1);
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) qf[qt][ds] = ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8);
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) pin_loaded(qf[qt][ds]);
+    }
+
+    int kv_end = sk_len;
+    if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
+    const int nblk = kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0;
+    const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+    const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+
+    f32x4 oacc[DT][QT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) oacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 lacc[QT];  // row sums on the matrix pipe: every row of this accumulator holds sum_k P[k][q]
+    float m_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        m_run[qt] = -INFINITY;
+    }
+    const float sl2 = P.scale * kLog2e;
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+
+    char* const Kb0 = smem;
+    char* const Vb0 = smem + 2 * TILE;
+    Stage sk, sv;
+    const uint32_t goff = Stage::thread_goff(P.k_ss, tid);
+    auto gload_tile = [&](Stage& st, const bf16* base, int row0) {
+        if (row0 + BKV <= sk_len)
+            st.gload_full(base, P.k_ss, row0, goff);
+        else
+            st.gload(base, P.k_ss, row0, sk_len, tid);
+    };
+    // a wave takes part in tile j iff one of its queries can see one of the tile's keys
+    auto active = [&](int j) { return (wq0 < sq_len) && !(CAUSAL && j * BKV > wq0 + QT * 16 - 1 + coff); };
+    // Online-softmax bookkeeping of one 32-key half: mask (diagonal / ragged tiles only), row max, and the RARE rescale.
+    // The running max is only advanced when some row's max grew by more than 2^kDefer (in the exp2 domain): otherwise the
+    // probabilities of this half are taken against the old max (they are then bounded by 2^kDefer instead of 1, harmless in
+    // fp32 / bf16 and invisible in O = sum(P V) / sum(P)), and neither O nor the row sums need the multiply.  Returns the
+    // exponent offsets.  Everything that follows (exp2 + bf16 pack) is branch-free, so the compiler interleaves it with the
+    // MFMAs of the next group.
+    constexpr float kDefer = 6.0f;
+    auto max_half = [&](f32x4 (&s)[2][QT], int kbase_idx, bool need_mask, float (&nm)[QT]) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            if (need_mask) {
+                const int qidx = wq0 + qt * 16 + t;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kidx = kbase_idx + kt * 16 + g * 4 + r;
+                        const bool dead = kidx >= sk_len || (CAUSAL && kidx > qidx + coff);
+                        s[kt][qt][r] = dead ? -INFINITY : s[kt][qt][r];
+                    }
+            }
+            float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
+                             fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
+            mx = group_max4<D>(mx);
+            const float m_new = fmaxf(m_run[qt], mx);
+            const bool grow = (m_new - m_run[qt]) * sl2 > kDefer || m_run[qt] == -INFINITY;
+            if (__any(grow && m_new != -INFINITY)) {  // wave-uniform, rare after the first tiles
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = (m_run[qt] == -INFINITY) ? 0.f : fast_exp2((m_run[qt] - m_use) * sl2);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
+                lacc[qt] *= alpha;
+                m_run[qt] = m_new;
+            }
+            nm[qt] = (m_run[qt] == -INFINITY) ? 0.f : -m_run[qt] * sl2;
+        }
+    };
+    // exp2 + bf16 pack of elements [e0, e0 + n) of a half (element e: qt = e / 8, slot = e % 8; slot < 4 -> key tile 0 of the
+    // half).  The packed words are pinned with an empty asm at the point where they are produced: LLVM otherwise SINKS the
+    // whole exponential chain into the block of its first use (the P V MFMAs), i.e. behind the MFMAs it is meant to overlap.
+    auto exp_slice = [&](const f32x4 (&s)[2][QT], const float (&nm)[QT], bf16x8 (&pb)[QT], int e0, int n) {
+#pragma unroll
+        for (int e = e0; e < e0 + n; e += 2) {
+            const int qt = e >> 3, sl = e & 7;
+            bf16x2 w;
+            w[0] = (bf16)fast_exp2(fmaf(s[sl >> 2][qt][sl & 3], sl2, nm[qt]));
+            w[1] = (bf16)fast_exp2(fmaf(s[(sl + 1) >> 2][qt][(sl + 1) & 3], sl2, nm[qt]));
+            uint32_t u = __builtin_bit_cast(uint32_t, w);
+            asm volatile("" : "+v"(u));
+            w = __builtin_bit_cast(bf16x2, u);
+            pb[qt][sl] = w[0];
+            pb[qt][sl + 1] = w[1];
+        }
+    };
+    constexpr int NE = QT * 8;  // exp elements per half
+    // {S^T of half hh (MFMA)} interleaved IN PROGRAM ORDER with {exp2/pack of the previous half (VALU)}: one K fragment read
+    // ahead, QT MFMAs, a slice of the exponentials; sched_barrier keeps the compiler from regrouping the two streams.
+    auto qk_half_exp = [&](f32x4 (&s)[2][QT], const char* kt_, int hh, const f32x4 (&sp_)[2][QT], const float (&nmp)[QT],
+                           bf16x8 (&pbp)[QT], bool with_exp) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int NS = DS * 2;
+        bf16x8 kf = Img::frag_row(kt_, (2 * hh) * 16, 0, lane);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int ds = st >> 1, kt = st & 1;
+            bf16x8 kn = kf;
+            if (st + 1 < NS) kn = Img::frag_row(kt_, (2 * hh + ((st + 1) & 1)) * 16, (st + 1) >> 1, lane);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+                s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s[kt][qt], 0, 0, 0);
+            if (with_exp) exp_slice(sp_, nmp, pbp, st * NE / NS, NE / NS);
+            kf = kn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // {O^T += V^T P^T of half hh (MFMA)} interleaved with {exp2/pack of the NEXT half}
+    auto pv_half_exp = [&](const bf16x8 (&pb)[QT], const char* vt_, int hh, const f32x4 (&sn_)[2][QT], const float (&nmn)[QT],
+                           bf16x8 (&pbn)[QT], bool with_exp) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qt], lacc[qt], 0, 0, 0);
+        bf16x8 va = Img::frag_col(vt_, 0, (2 * hh) * 16, (2 * hh + 1) * 16, lane);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            bf16x8 vn = va;
+            if (dt + 1 < DT) vn = Img::frag_col(vt_, (dt + 1) * 16, (2 * hh) * 16, (2 * hh + 1) * 16, lane);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qt], oacc[dt][qt], 0, 0, 0);
+            if (with_exp) exp_slice(sn_, nmn, pbn, dt * NE / DT, NE / DT);
+            va = vn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- prologue: tile 0 -> LDS
+    if (nblk > 0) {
+        gload_tile(sk, kbase, 0);
+        gload_tile(sv, vbase, 0);
+        sk.lstore_row(Kb0, tid);
+        sv.lstore_col(Vb0, tid);
+    }
+    __syncthreads();
+
+    for (int j = 0; j < nblk; ++j) {
+        const int kv0 = j * BKV;
+        if (j + 1 < nblk) {  // next tile's global loads fly under this tile's compute
+            gload_tile(sk, kbase, kv0 + BKV);
+            gload_tile(sv, vbase, kv0 + BKV);
+        }
+        const char* kt_ = Kb0 + (j & 1) * TILE;
+        const char* vt_ = Vb0 + (j & 1) * TILE;
+        if (active(j)) {
+            const bool need_mask = (kv0 + BKV > sk_len) || (CAUSAL && (kv0 + BKV - 1 > wq0 + coff));
+            f32x4 sa[2][QT], sb[2][QT];
+            bf16x8 pa[QT], pbb[QT];
+            float nma[QT], nmb[QT];
+            qk_half_exp(sa, kt_, 0, sa, nma, pa, false);
+            max_half(sa, kv0, need_mask, nma);
+            qk_half_exp(sb, kt_, 1, sa, nma, pa, true);      // S of keys 32..63 under the exponentials of keys 0..31
+            max_half(sb, kv0 + 32, need_mask, nmb);
+            pv_half_exp(pa, vt_, 0, sb, nmb, pbb, true);     // P V of keys 0..31 under the exponentials of keys 32..63
+            pv_half_exp(pbb, vt_, 1, sb, nmb, pbb, false);
+        }
+        if (j + 1 < nblk) {
+            sk.lstore_row(Kb0 + ((j + 1) & 1) * TILE, tid);
+            sv.lstore_col(Vb0 + ((j + 1) & 1) * TILE, tid);
+        }
+        __syncthreads();
+    }
+
+    // finalize: lane holds O^T[d = dt*16 + g*4 + r][q = t] of tile qt; every row of lacc holds the row sum of query t
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const float l = lacc[qt][0];
+        const int qrow = wq0 + qt * 16 + t;
+        const bool valid = qrow < sq_len;
+        const float inv = (l > 0.f && valid) ? 1.0f / l : 0.f;
+        if (qrow < SqE) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (bf16)(oacc[dt][qt][r] * inv);
+                st_bf16x4(obase + (int64_t)qrow * P.o_ss + dt * 16 + g * 4, o);
+            }
+            if (lsebase && g == 0) lsebase[qrow] = (valid && l > 0.f) ? (m_run[qt] * P.scale + logf(l)) : 0.f;
+        }
+    }
+}
+
+template <int D, bool CAUSAL>
+int launch_fwd8(const AttnParams& P, hipStream_t stream) {
+    constexpr int LDS = 4 * 64 * D * 2;
+    static std::atomic<uint64_t> lds_ok{0};
+    dllm_ensure_dyn_lds(&attn_fwd8_kernel<D, CAUSAL>, LDS, lds_ok);
+    dim3 grid((P.Sq + 255) / 256, P.H, P.B);
+    hipLaunchKernelGGL((attn_fwd8_kernel<D, CAUSAL>), grid, dim3(512), LDS, stream, P);
+    return dllm_check_launch();
+}
+
+template <int D, bool CAUSAL, int ABL = 0>
 int launch_fwd(const AttnParams& P, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * 64 * D * 2;
     static std::atomic<uint64_t> lds_ok{0};
-    dllm_ensure_dyn_lds(&attn_fwd_kernel<D, CAUSAL>, LDS, lds_ok);
+    dllm_ensure_dyn_lds(&attn_fwd_kernel<D, CAUSAL, ABL>, LDS, lds_ok);
     dim3 grid((P.Sq + 127) / 128, P.H, P.B);
-    hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL>), grid, dim3(256), LDS, stream, P);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, ABL>), grid, dim3(256), LDS, stream, P);
     return dllm_check_launch();
 }
 
@@ -253,8 +555,46 @@ int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     P.q_sb = q_sb; P.q_ss = q_ss; P.q_sh = q_sh; P.k_sb = k_sb; P.k_ss = k_ss; P.k_sh = k_sh;
     P.o_sb = o_sb; P.o_ss = o_ss; P.o_sh = o_sh; P.scale = scale; P.causal = causal;
     hipStream_t s = (hipStream_t)stream;
+    // kernel choice: bit 1 of `causal` forces the 4-wave kernel, bit 2 the 8-wave pipelined one (tests cover both on every
+    // shape); automatic = 8-wave for long query sequences, 4-wave (128-query blocks fill the chip better) for short ones
+    const int force = causal >> 1;
+    causal &= 1;
+    P.causal = causal;
+    const bool wide = force == 2 || (force == 0 && Sq >= 512);
+    if (wide) {
+        if (D == 128) return causal ? launch_fwd8<128, true>(P, s) : launch_fwd8<128, false>(P, s);
+        return causal ? launch_fwd8<64, true>(P, s) : launch_fwd8<64, false>(P, s);
+    }
     if (D == 128) return causal ? launch_fwd<128, true>(P, s) : launch_fwd<128, false>(P, s);
     return causal ? launch_fwd<64, true>(P, s) : launch_fwd<64, false>(P, s);
 }
+
+#ifdef DLLM_BENCH_MODES
+// benchmark-only: the causal head_dim-128 forward with one cost removed (see ABL above); results are wrong by design
+int dllm_attn_fwd_ablate(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Sq, int D, int abl,
+                         void* stream) {
+    if (D != 128) return DLLM_ERR_SHAPE;
+    AttnParams P{};
+    P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.o = (bf16*)o; P.lse = lse;
+    P.B = B; P.H = H; P.Hkv = H; P.Sq = Sq; P.Sk = Sq;
+    P.q_sb = P.k_sb = P.o_sb = (int64_t)Sq * H * D; P.q_ss = P.k_ss = P.o_ss = (int64_t)H * D; P.q_sh = P.k_sh = P.o_sh = D;
+    P.scale = 0.08838834764f; P.causal = 1;
+    hipStream_t s = (hipStream_t)stream;
+    switch (abl) {
+        case 0: return launch_fwd<128, true, 0>(P, s);
+        case 1: return launch_fwd<128, true, 1>(P, s);
+        case 2: return launch_fwd<128, true, 2>(P, s);
+        case 4: return launch_fwd<128, true, 4>(P, s);
+        case 8: return launch_fwd<128, true, 8>(P, s);
+        case 16: return launch_fwd<128, true, 16>(P, s);
+        case 3: return launch_fwd<128, true, 3>(P, s);
+        case 6: return launch_fwd<128, true, 6>(P, s);
+        case 7: return launch_fwd<128, true, 7>(P, s);
+        case 15: return launch_fwd<128, true, 15>(P, s);
+        case 9: return launch_fwd<128, true, 9>(P, s);
+        default: return DLLM_ERR_SHAPE;
+    }
+}
+#endif
 
 }  // extern "C"

@@ -85,7 +85,9 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const bf16* __restrict__ d
             }
             oa[e] = (bf16)(d * y * dact);
             ob[e] = (bf16)(d * act);
-            oc[e] = (bf16)(act * y);  // the forward product, recomputed in the same pass for the down-projection's weight gradient
+            // the forward product, recomputed in the same pass for the down-projection's weight gradient: bit-identical to
+            // glu_fwd_kernel (same silu_f / gelu_erf_f expression, one rounding)
+            oc[e] = (bf16)((MODE == 0 ? silu_f(x) : act) * y);
         }
         st_bf16x8(da + r * ldda + c, oa);
         st_bf16x8(db + r * lddb + c, ob);

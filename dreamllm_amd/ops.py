@@ -54,6 +54,11 @@ SPLITK = True  # split-K for small grids with deep reductions (see dllm_gemm_spl
 GEMM_VARIANT = 0
 
 
+# Attention forward kernel choice handed to dllm_attn_fwd in bits 1-2 of `causal` (include/dreamllm_hip.h): 0 automatic, 1 the
+# 4-wave 128-query kernel, 2 the 8-wave pipelined 256-query kernel.  Tests run every shape through both.
+ATTN_VARIANT = 0
+
+
 class gemm_variant:
     def __init__(self, tile=0, group_m=0):
         self.v = int(tile) | (int(group_m) << 16)
@@ -270,7 +275,7 @@ def attn_fwd(q, k, v, causal, scale=None, seqlens=None, need_lse=True, seqstart=
     lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_lse else None
     check("dllm_attn_fwd", _p(q), _p(k), _p(v), _p(o), _p(lse), _p(seqlens), _p(seqstart), B, H, Hkv, Sq, Sk, D, q.stride(0), q.stride(1),
           q.stride(2), k.stride(0), k.stride(1), k.stride(2), o.stride(0), o.stride(1), o.stride(2), float(scale),
-          int(causal), _stream())
+          int(bool(causal)) | (ATTN_VARIANT << 1), _stream())
     return o, lse
 
 

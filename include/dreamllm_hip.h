@@ -104,7 +104,9 @@ int dllm_sumpool2_nhwc(const void* in, void* out, int NB, int H, int W, int C, v
  * keys outside the span are masked, query rows outside it come back as zeros; with Sq != Sk (KV cache) seqstart masks the
  * leading keys and every query is valid), CLIP self-attention and the UNet self/cross attention [ext].
  * q,o: [B,Sq,H,D] views (element strides sb,ss,sh; d contiguous); k,v: [B,Sk,Hkv,D] views sharing one stride set;
- * D in {64,128}; H % Hkv == 0 (GQA, repeat_kv :242-251); seqlens / seqstart int32[B] or NULL; lse fp32 [B,H,Sq] or NULL. */
+ * D in {64,128}; H % Hkv == 0 (GQA, repeat_kv :242-251); seqlens / seqstart int32[B] or NULL; lse fp32 [B,H,Sq] or NULL.
+ * `causal`: bit 0 = causal mask; bits 1-2 select the forward kernel per call (0 automatic: the 8-wave software-pipelined
+ * 256-query kernel for Sq >= 512, the 4-wave 128-query kernel below; 1 / 2 force one of them -- tests run both everywhere). */
 int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, const int* seqstart, int B,
                   int H, int Hkv, int Sq, int Sk, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
                   int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale, int causal, void* stream);

@@ -256,6 +256,15 @@ def attn_ref(q, k, v, causal, seqlen=None):
     return o.transpose(1, 2), lse
 
 
+@pytest.fixture(params=[1, 2], ids=["fwd4wave", "fwd8wave"])
+def attn_variant(request):
+    """every forward-attention test runs on both kernels (4-wave 128-query blocks / 8-wave pipelined 256-query blocks)"""
+    from dreamllm_amd import ops
+    ops.ATTN_VARIANT = request.param
+    yield request.param
+    ops.ATTN_VARIANT = 0
+
+
 @pytest.mark.parametrize("B,H,Hkv,Sq,Sk,D,causal", [
     (2, 4, 4, 128, 128, 128, True),
     (1, 2, 2, 300, 300, 128, True),
@@ -264,8 +273,11 @@ def attn_ref(q, k, v, causal, seqlen=None):
     (1, 4, 2, 160, 160, 128, True),    # GQA
     (1, 2, 2, 64, 200, 64, False),
     (1, 1, 1, 1024, 1024, 64, False),
+    (1, 2, 2, 777, 777, 128, True),    # several 256-query blocks, ragged tail
+    (2, 2, 1, 513, 513, 64, True),
+    (1, 2, 2, 40, 600, 128, True),     # KV cache: few queries at the end of a long key axis
 ])
-def test_attn_fwd(B, H, Hkv, Sq, Sk, D, causal):
+def test_attn_fwd(B, H, Hkv, Sq, Sk, D, causal, attn_variant):
     ops = _ops()
     torch.manual_seed(Sq + Sk + D)
     q, k, v = rnd(B, Sq, H, D), rnd(B, Sk, Hkv, D), rnd(B, Sk, Hkv, D)
@@ -275,7 +287,7 @@ def test_attn_fwd(B, H, Hkv, Sq, Sk, D, causal):
     assert rel_l2(lse, lref) < 1e-4
 
 
-def test_attn_fwd_strided_qkv_and_padding():
+def test_attn_fwd_strided_qkv_and_padding(attn_variant):
     """q/k/v as strided views of one fused [B,S,3,H,D] buffer; right padding handled through seqlens."""
     ops = _ops()
     torch.manual_seed(11)
@@ -292,7 +304,7 @@ def test_attn_fwd_strided_qkv_and_padding():
         assert torch.count_nonzero(o[b, L:]) == 0  # pad_input semantics: zeros at padded positions
 
 
-def test_attn_fwd_outlier_rescale():
+def test_attn_fwd_outlier_rescale(attn_variant):
     """Force the online-softmax rescale branch: one key dominates late in the sequence."""
     ops = _ops()
     torch.manual_seed(2)
@@ -303,6 +315,27 @@ def test_attn_fwd_outlier_rescale():
     o, lse = ops.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), True)
     assert rel_l2(o, oref) < 6e-3
     assert rel_l2(lse, lref) < 1e-4
+
+
+@pytest.mark.parametrize("ramp", [0.02, 0.2, 1.0])
+def test_attn_fwd_deferred_max_ramp(ramp, attn_variant):
+    """The 8-wave kernel advances a row's running max only when it grows by more than 2^6 within a 32-key half (otherwise the
+    probabilities are taken against the stale max and are > 1).  Keys whose scores ramp up along the sequence exercise every
+    regime: growth below the threshold for many consecutive tiles (stale max, P up to 64), growth above it (rescale), and a
+    spike (first-tile style jump).  Full-tensor fp32 reference, as the branch is data dependent (guide rule 26)."""
+    ops = _ops()
+    torch.manual_seed(7)
+    B, S, H, D = 1, 768, 2, 128
+    q, k, v = rnd(B, S, H, D), rnd(B, S, H, D), rnd(B, S, H, D)
+    u = torch.nn.functional.normalize(torch.randn(D), dim=0)
+    q = bf16r(q + 4.0 * u)                                                   # every query has a large component along u
+    k = bf16r(k + ramp * 0.05 * torch.arange(S)[None, :, None, None] * u)    # keys drift along u: scores rise with the key index
+    k[0, 700] = bf16r(q[0, 730] * 2.0)                                       # and one spike
+    for causal in (True, False):
+        oref, lref = attn_ref(q, k, v, causal)
+        o, lse = ops.attn_fwd(q.to(BF).to(DEV), k.to(BF).to(DEV), v.to(BF).to(DEV), causal)
+        assert rel_l2(o, oref) < 6e-3, (causal, ramp)
+        assert (lse.cpu() - lref).abs().max() < 2e-3 * max(1.0, lref.abs().max().item()), (causal, ramp)
 
 
 # ----------------------------------------------------------------------------- elementwise / gather / loss / optimizer

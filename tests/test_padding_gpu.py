@@ -32,14 +32,22 @@ def _ref_attn(q, k, v, key_ok, q_ok, causal_off):
     return o * q_ok[:, None]
 
 
+@pytest.fixture(params=[1, 2], ids=["fwd4wave", "fwd8wave"])
+def attn_variant(request):
+    from dreamllm_amd import ops
+    ops.ATTN_VARIANT = request.param
+    yield request.param
+    ops.ATTN_VARIANT = 0
+
+
 @pytest.mark.parametrize("D,H,Hkv", [(128, 2, 2), (64, 4, 2)])
-def test_attention_spans_fwd_bwd(D, H, Hkv):
+def test_attention_spans_fwd_bwd(D, H, Hkv, attn_variant):
     """seqstart / seqlens: left padding, right padding, both, an empty row, a full row -- forward, LSE-consistent backward
     (dQ, dK, dV) and zeros at every pad row."""
     from dreamllm_amd import ops
     torch.manual_seed(D)
-    S = 200
-    spans = [(0, 200), (37, 163), (0, 129), (64, 100), (5, 0), (199, 1)]
+    S = 200 if attn_variant == 1 else 600
+    spans = [(0, S), (37, S - 37), (0, 129), (64, 100), (5, 0), (S - 1, 1), (S // 2, S // 3)]
     B = len(spans)
     q, k, v = (bf16r(torch.randn(B, S, H, D)) for _ in range(3))
     k = k[:, :, :Hkv].contiguous()
@@ -69,7 +77,7 @@ def test_attention_spans_fwd_bwd(D, H, Hkv):
             assert float(t[b][pad.to(DEV)].float().abs().sum()) == 0.0
 
 
-def test_attention_seqstart_with_cache():
+def test_attention_seqstart_with_cache(attn_variant):
     """Sq != Sk (KV cache): seqstart masks the first keys of each row, every query is valid and sits at the end of the keys."""
     from dreamllm_amd import ops
     torch.manual_seed(1)
