@@ -11,6 +11,7 @@
 // 16x16x32 bf16: a lane owns one query column, so the running max / sum / rescale are lane-local and the
 // probabilities feed the PV MFMA straight from registers (no LDS round trip, no permutes).
 #include "attn_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -254,14 +255,53 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 //     under the softmax's VALU instructions (K runs one tile ahead of V in LDS; scores are double-buffered in registers).
 //   * softmax diet: row max through v_permlane16/32_swap (no LDS round trip of ds_bpermute), row sums on the matrix pipe
 //     (one extra MFMA with an all-ones A operand per 32 keys instead of 32 VALU adds per lane), v_max3 / cvt_pk by the compiler.
-template <int D>
-__device__ __forceinline__ float group_max4(float x) {  // max over the 4 lanes {t, t+16, t+32, t+48}
+#define GLDS16_(gptr, lptr)                                                                                            \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                           \
+                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
+
+__device__ __forceinline__ uint32_t lds_addr32(const char* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ bf16x8 join2(u32x2 lo, u32x2 hi) {
+    union {
+        struct { u32x2 a, b; } s;
+        bf16x8 v;
+    } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.v;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_<I + 1, N>(f);
+    }
+}
+
+constexpr float kNegBig = -1.0e30f;
+
+// single-instruction maxima: with NaNs possible (-fno-finite-math-only: the masks use infinities) fmaxf() costs an extra
+// canonicalising v_max per MFMA output; the scores here are never NaN
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float vmax2(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// max(seed, x over the 4 lanes {t, t+16, t+32, t+48})
+__device__ __forceinline__ float group_max4(float x, float seed) {
     const uint32_t u = __float_as_uint(x);
     auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const float m = vmax2(__uint_as_float(a[0]), __uint_as_float(a[1]));
     const uint32_t v = __float_as_uint(m);
     auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    return vmax3(seed, __uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 template <int D, bool CAUSAL>
@@ -272,7 +312,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
     constexpr int DS = D / 32, DT = D / 16;
     constexpr int TILE = BKV * D * 2;
     using Img = TileImg<D>;
-    using Stage = TileStage<D, BKV, 512>;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // K[2] then V[2]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -339,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        m_run[qt] = -INFINITY;
+        m_run[qt] = kNegBig;  // finite "minus infinity": no special cases in the bookkeeping (exp2 of -huge is exactly 0)
     }
     const float sl2 = P.scale * kLog2e;
     bf16x8 ones;
@@ -348,13 +387,35 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
 
     char* const Kb0 = smem;
     char* const Vb0 = smem + 2 * TILE;
-    Stage sk, sv;
-    const uint32_t goff = Stage::thread_goff(P.k_ss, tid);
-    auto gload_tile = [&](Stage& st, const bf16* base, int row0) {
-        if (row0 + BKV <= sk_len)
-            st.gload_full(base, P.k_ss, row0, goff);
-        else
-            st.gload(base, P.k_ss, row0, sk_len, tid);
+    // K / V tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass, no address VALU per
+    // store).  The DMA writes wave-uniform base + lane * 16, so the XOR swizzles of the two LDS images are applied to the
+    // per-lane SOURCE chunk (a permutation inside one row: coalescing is unaffected).  A wave moves NDMA 1-KiB groups of RPG
+    // rows per tile; every LDS read of this kernel is inline asm (below), so hipcc has no visible LDS read in front of which it
+    // would drain the DMA queue.
+    constexpr int CPR = D / 8;             // 16-byte chunks per row
+    constexpr int RPG = 64 / CPR;          // rows per 1-KiB group (4 at D = 128, 8 at D = 64)
+    constexpr int NDMA = (BKV / RPG) / NW; // groups per wave per tile (2 / 1)
+    const int drow = lane / CPR, dpos = lane % CPR;
+    int k_src_chunk[NDMA], v_src_chunk[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int r = (wave * NDMA + i) * RPG + drow;
+        if constexpr (D == 128) {
+            k_src_chunk[i] = dpos ^ (r & 15);
+            v_src_chunk[i] = (((dpos >> 1) ^ (r & 7)) << 1) | (dpos & 1);
+        } else {
+            k_src_chunk[i] = dpos ^ ((r >> 1) & 7);
+            v_src_chunk[i] = (((dpos >> 1) ^ ((r >> 1) & 3)) << 1) | (dpos & 1);
+        }
+    }
+    auto dma_tile = [&](int row0, int buf) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int grp = wave * NDMA + i;
+            const int row = min(row0 + grp * RPG + drow, sk_len - 1);  // rows past the end: any finite data (masked later)
+            GLDS16_(kbase + (int64_t)row * P.k_ss + k_src_chunk[i] * 8, Kb0 + buf * TILE + grp * 1024);
+            GLDS16_(vbase + (int64_t)row * P.k_ss + v_src_chunk[i] * 8, Vb0 + buf * TILE + grp * 1024);
+        }
     };
     // a wave takes part in tile j iff one of its queries can see one of the tile's keys
     auto active = [&](int j) { return (wq0 < sq_len) && !(CAUSAL && j * BKV > wq0 + QT * 16 - 1 + coff); };
@@ -365,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
     // exponent offsets.  Everything that follows (exp2 + bf16 pack) is branch-free, so the compiler interleaves it with the
     // MFMAs of the next group.
     constexpr float kDefer = 6.0f;
-    auto max_half = [&](f32x4 (&s)[2][QT], int kbase_idx, bool need_mask, float (&nm)[QT]) {
+    auto max_half = [&](f32x4 (&s)[2][QT], int kbase_idx, bool need_mask, float (&nm)[QT], bf16x8 (*pending)[QT]) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             if (need_mask) {
@@ -379,20 +440,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
                         s[kt][qt][r] = dead ? -INFINITY : s[kt][qt][r];
                     }
             }
-            float mx = fmaxf(fmaxf(fmaxf(s[0][qt][0], s[0][qt][1]), fmaxf(s[0][qt][2], s[0][qt][3])),
-                             fmaxf(fmaxf(s[1][qt][0], s[1][qt][1]), fmaxf(s[1][qt][2], s[1][qt][3])));
-            mx = group_max4<D>(mx);
-            const float m_new = fmaxf(m_run[qt], mx);
-            const bool grow = (m_new - m_run[qt]) * sl2 > kDefer || m_run[qt] == -INFINITY;
-            if (__any(grow && m_new != -INFINITY)) {  // wave-uniform, rare after the first tiles
-                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                const float alpha = (m_run[qt] == -INFINITY) ? 0.f : fast_exp2((m_run[qt] - m_use) * sl2);
+            float mx = vmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
+            mx = vmax3(mx, s[0][qt][3], s[1][qt][0]);
+            mx = vmax3(mx, s[1][qt][1], s[1][qt][2]);
+            mx = vmax2(mx, s[1][qt][3]);
+            const float m_new = group_max4(mx, m_run[qt]);
+            if (__any((m_new - m_run[qt]) * sl2 > kDefer)) {  // wave-uniform, rare after the first tiles
+                const float alpha = fast_exp2((m_run[qt] - m_new) * sl2);  // 0 while the old max is the finite "minus infinity"
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
                 lacc[qt] *= alpha;
+                // probabilities of the previous half were exponentiated against the OLD max and have not entered O / the row
+                // sums yet: they take the same factor (everything still at the old scale is rescaled exactly once)
+                if (pending != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) (*pending)[qt][e] = (bf16)((float)(*pending)[qt][e] * alpha);
+                }
                 m_run[qt] = m_new;
             }
-            nm[qt] = (m_run[qt] == -INFINITY) ? 0.f : -m_run[qt] * sl2;
+            nm[qt] = -m_run[qt] * sl2;  // a row that has seen no key yet: +huge, and exp2(-inf + huge) = 0
         }
     };
     // exp2 + bf16 pack of elements [e0, e0 + n) of a half (element e: qt = e / 8, slot = e % 8; slot < 4 -> key tile 0 of the
@@ -413,81 +479,111 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
         }
     };
     constexpr int NE = QT * 8;  // exp elements per half
-    // {S^T of half hh (MFMA)} interleaved IN PROGRAM ORDER with {exp2/pack of the previous half (VALU)}: one K fragment read
-    // ahead, QT MFMAs, a slice of the exponentials; sched_barrier keeps the compiler from regrouping the two streams.
-    auto qk_half_exp = [&](f32x4 (&s)[2][QT], const char* kt_, int hh, const f32x4 (&sp_)[2][QT], const float (&nmp)[QT],
-                           bf16x8 (&pbp)[QT], bool with_exp) {
+
+    // ---- the fragment stream of one tile: 32 steps = {K frags of keys 0..31} {K frags of keys 32..63} {V frags 0..31} {V frags
+    // 32..63}, DS*2 / DT steps each (D = 128: 8 / 8 / 8 / 8).  Every LDS read is inline asm, requested PRE steps ahead of its
+    // MFMAs and retired by a COUNTED s_waitcnt lgkmcnt(n) (LDS returns in order): with the compiler's own placement each step
+    // waited out a full LDS round trip (~200 cycles x 32 steps per tile -- the reason the 4-wave kernel ran its MFMAs 10 % of
+    // the time).  Steps are compile-time indices, so ring slots and immediates are static.
+    constexpr int NSK = DS * 2, NSV = DT;                 // steps per K half / per V half
+    constexpr int NSTEP = 2 * NSK + 2 * NSV;
+    constexpr int PRE = 5;                                // fragments in flight (<= 15 LDS operations outstanding)
+    constexpr int RING = PRE + 1;
+    u32x4 kring[RING];
+    u32x2 vlo[RING], vhi[RING];
+    // per-lane LDS byte addresses (tile buffer 0): K row image at (row t, chunk ds*4 + g), V col image at (row g*4 + t/4, d = 4*(t&3))
+    uint32_t kaddr0[DS];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int NS = DS * 2;
-        bf16x8 kf = Img::frag_row(kt_, (2 * hh) * 16, 0, lane);
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-            const int ds = st >> 1, kt = st & 1;
-            bf16x8 kn = kf;
-            if (st + 1 < NS) kn = Img::frag_row(kt_, (2 * hh + ((st + 1) & 1)) * 16, (st + 1) >> 1, lane);
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-                s[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], s[kt][qt], 0, 0, 0);
-            if (with_exp) exp_slice(sp_, nmp, pbp, st * NE / NS, NE / NS);
-            kf = kn;
-            __builtin_amdgcn_sched_barrier(0);
+    for (int ds = 0; ds < DS; ++ds) kaddr0[ds] = lds_addr32(Kb0 + Img::row_off(t, ds * 4 + g));
+    const uint32_t vaddr0 = lds_addr32(Vb0 + (g * 4 + (t >> 2)) * Img::PITCH + (t & 3) * 8);
+    const uint32_t vswz = (uint32_t)((D == 128 ? ((g * 4 + (t >> 2)) & 7) : (((g * 4 + (t >> 2)) >> 1) & 3)) << 5);
+    uint32_t kaddr[DS], vaddr = vaddr0;
+    auto frag_ops = [](int f) { return f < 2 * NSK ? 1 : 2; };  // LDS operations of fragment f
+    auto issue = [&kring, &vlo, &vhi, &kaddr, &vaddr, vswz](auto fc) {
+        constexpr int f = decltype(fc)::value;
+        if constexpr (f < 2 * NSK) {
+            constexpr int hh = f / NSK, ds = (f % NSK) >> 1, kt = (f % NSK) & 1;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kring[f % RING]) : "v"(kaddr[ds]), "n"((2 * hh + kt) * 16 * Img::PITCH));
+        } else {
+            constexpr int hh = (f - 2 * NSK) / NSV, dt = (f - 2 * NSK) % NSV;
+            const uint32_t a = vaddr + ((uint32_t)(dt << 5) ^ vswz);
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[f % RING]) : "v"(a), "n"((2 * hh) * 16 * Img::PITCH));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[f % RING]) : "v"(a), "n"((2 * hh + 1) * 16 * Img::PITCH));
         }
     };
-    // {O^T += V^T P^T of half hh (MFMA)} interleaved with {exp2/pack of the NEXT half}
-    auto pv_half_exp = [&](const bf16x8 (&pb)[QT], const char* vt_, int hh, const f32x4 (&sn_)[2][QT], const float (&nmn)[QT],
-                           bf16x8 (&pbn)[QT], bool with_exp) {
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pb[qt], lacc[qt], 0, 0, 0);
-        bf16x8 va = Img::frag_col(vt_, 0, (2 * hh) * 16, (2 * hh + 1) * 16, lane);
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            bf16x8 vn = va;
-            if (dt + 1 < DT) vn = Img::frag_col(vt_, (dt + 1) * 16, (2 * hh) * 16, (2 * hh + 1) * 16, lane);
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb[qt], oacc[dt][qt], 0, 0, 0);
-            if (with_exp) exp_slice(sn_, nmn, pbn, dt * NE / DT, NE / DT);
-            va = vn;
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    auto wait_frag = [&kring, &vlo, &vhi](auto fc) {  // retire fragment f: everything requested after it may stay in flight
+        constexpr int f = decltype(fc)::value;
+        constexpr int last = f + PRE < NSTEP ? f + PRE : NSTEP - 1;
+        constexpr int younger = [](int f0, int l0) { int n = 0; for (int i = f0 + 1; i <= l0; ++i) n += (i < 2 * (D / 32) * 2 ? 1 : 2); return n; }(f, last);
+        static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
+        if constexpr (f < 2 * NSK)
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kring[f % RING]) : "n"(younger) : "memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(vlo[f % RING]), "+v"(vhi[f % RING]) : "n"(younger) : "memory");
     };
+    (void)frag_ops;
 
     // ---- prologue: tile 0 -> LDS
-    if (nblk > 0) {
-        gload_tile(sk, kbase, 0);
-        gload_tile(sv, vbase, 0);
-        sk.lstore_row(Kb0, tid);
-        sv.lstore_col(Vb0, tid);
-    }
+    if (nblk > 0) dma_tile(0, 0);
     __syncthreads();
 
     for (int j = 0; j < nblk; ++j) {
         const int kv0 = j * BKV;
-        if (j + 1 < nblk) {  // next tile's global loads fly under this tile's compute
-            gload_tile(sk, kbase, kv0 + BKV);
-            gload_tile(sv, vbase, kv0 + BKV);
-        }
-        const char* kt_ = Kb0 + (j & 1) * TILE;
-        const char* vt_ = Vb0 + (j & 1) * TILE;
+        if (j + 1 < nblk) dma_tile(kv0 + BKV, (j + 1) & 1);  // the next tile flies under this tile's compute
         if (active(j)) {
+            const uint32_t boff = (uint32_t)((j & 1) * TILE);
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) kaddr[ds] = kaddr0[ds] + boff;
+            vaddr = vaddr0 + boff;
             const bool need_mask = (kv0 + BKV > sk_len) || (CAUSAL && (kv0 + BKV - 1 > wq0 + coff));
             f32x4 sa[2][QT], sb[2][QT];
             bf16x8 pa[QT], pbb[QT];
             float nma[QT], nmb[QT];
-            qk_half_exp(sa, kt_, 0, sa, nma, pa, false);
-            max_half(sa, kv0, need_mask, nma);
-            qk_half_exp(sb, kt_, 1, sa, nma, pa, true);      // S of keys 32..63 under the exponentials of keys 0..31
-            max_half(sb, kv0 + 32, need_mask, nmb);
-            pv_half_exp(pa, vt_, 0, sb, nmb, pbb, true);     // P V of keys 0..31 under the exponentials of keys 32..63
-            pv_half_exp(pbb, vt_, 1, sb, nmb, pbb, false);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    sa[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    sb[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            static_for_<0, PRE>([&](auto fc) { issue(fc); });
+            static_for_<0, NSTEP>([&](auto sc) {
+                constexpr int st = decltype(sc)::value;
+                if constexpr (st + PRE < NSTEP) issue(std::integral_constant<int, st + PRE>{});
+                // segment boundaries: the short VALU-only bookkeeping of the online softmax
+                if constexpr (st == NSK) max_half(sa, kv0, need_mask, nma, nullptr);
+                if constexpr (st == 2 * NSK) max_half(sb, kv0 + 32, need_mask, nmb, &pa);
+                if constexpr (st == 2 * NSK || st == 2 * NSK + NSV) {  // row sums of the half entering P V, on the matrix pipe
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, st == 2 * NSK ? pa[qt] : pbb[qt], lacc[qt], 0, 0, 0);
+                }
+                wait_frag(sc);
+                if constexpr (st < 2 * NSK) {
+                    constexpr int hh = st / NSK, ds = (st % NSK) >> 1, kt = (st % NSK) & 1;
+                    const bf16x8 kf = __builtin_bit_cast(bf16x8, kring[st % RING]);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        if constexpr (hh == 0)
+                            sa[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], sa[kt][qt], 0, 0, 0);
+                        else
+                            sb[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], sb[kt][qt], 0, 0, 0);
+                    }
+                    // keys 32..63: under the exponentials of keys 0..31
+                    if constexpr (hh == 1) exp_slice(sa, nma, pa, (st - NSK) * NE / NSK, NE / NSK);
+                } else {
+                    constexpr int hh = (st - 2 * NSK) / NSV, dt = (st - 2 * NSK) % NSV;
+                    const bf16x8 va = join2(vlo[st % RING], vhi[st % RING]);
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, hh == 0 ? pa[qt] : pbb[qt], oacc[dt][qt], 0, 0, 0);
+                    // P V of keys 0..31: under the exponentials of keys 32..63
+                    if constexpr (hh == 0) exp_slice(sb, nmb, pbb, dt * NE / NSV, NE / NSV);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
-        if (j + 1 < nblk) {
-            sk.lstore_row(Kb0 + ((j + 1) & 1) * TILE, tid);
-            sv.lstore_col(Vb0 + ((j + 1) & 1) * TILE, tid);
-        }
-        __syncthreads();
+        __syncthreads();  // tile j + 1 has landed (vmcnt(0) of the DMA) and every wave is done reading tile j
     }
 
     // finalize: lane holds O^T[d = dt*16 + g*4 + r][q = t] of tile qt; every row of lacc holds the row sum of query t
