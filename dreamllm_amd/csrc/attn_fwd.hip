@@ -11,7 +11,6 @@
 // 16x16x32 bf16: a lane owns one query column, so the running max / sum / rescale are lane-local and the
 // probabilities feed the PV MFMA straight from registers (no LDS round trip, no permutes).
 #include "attn_common.h"
-#include <type_traits>
 
 namespace {
 
@@ -30,8 +29,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, t = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int qblk = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;  // heavy causal blocks first
+    constexpr int BQ_ = (4 * 2) * 16;
+    const int nqb = (P.Sq + BQ_ - 1) / BQ_;
+    const AttnBlock bm = attn_block_map(nqb, P.H, P.B);
+    if (!bm.valid) return;
+    const int b = bm.b, h = bm.h;
+    const int qblk = CAUSAL ? (nqb - 1 - bm.r) : bm.r;  // heavy causal blocks first
     const int hk = h / (P.H / P.Hkv);
     const AttnSpan sp = attn_span(P, b);
     const int sq_len = sp.sq_len, sk_len = sp.sk_len, SqE = sp.SqE;
@@ -255,30 +258,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
 //     under the softmax's VALU instructions (K runs one tile ahead of V in LDS; scores are double-buffered in registers).
 //   * softmax diet: row max through v_permlane16/32_swap (no LDS round trip of ds_bpermute), row sums on the matrix pipe
 //     (one extra MFMA with an all-ones A operand per 32 keys instead of 32 VALU adds per lane), v_max3 / cvt_pk by the compiler.
-#define GLDS16_(gptr, lptr)                                                                                            \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                           \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
-
-__device__ __forceinline__ uint32_t lds_addr32(const char* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
-}
-__device__ __forceinline__ bf16x8 join2(u32x2 lo, u32x2 hi) {
-    union {
-        struct { u32x2 a, b; } s;
-        bf16x8 v;
-    } u;
-    u.s.a = lo;
-    u.s.b = hi;
-    return u.v;
-}
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for_(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for_<I + 1, N>(f);
-    }
-}
-
 constexpr float kNegBig = -1.0e30f;
 
 // single-instruction maxima: with NaNs possible (-fno-finite-math-only: the masks use infinities) fmaxf() costs an extra
@@ -317,8 +296,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, t = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int qblk = CAUSAL ? (gridDim.x - 1 - blockIdx.x) : blockIdx.x;  // heavy causal blocks first
+    constexpr int BQ_ = (8 * 2) * 16;
+    const int nqb = (P.Sq + BQ_ - 1) / BQ_;
+    const AttnBlock bm = attn_block_map(nqb, P.H, P.B);
+    if (!bm.valid) return;
+    const int b = bm.b, h = bm.h;
+    const int qblk = CAUSAL ? (nqb - 1 - bm.r) : bm.r;  // heavy causal blocks first
     const int hk = h / (P.H / P.Hkv);
     const AttnSpan sp = attn_span(P, b);
     const int sq_len = sp.sq_len, sk_len = sp.sk_len, SqE = sp.SqE;
@@ -611,7 +594,7 @@ int launch_fwd8(const AttnParams& P, hipStream_t stream) {
     constexpr int LDS = 4 * 64 * D * 2;
     static std::atomic<uint64_t> lds_ok{0};
     dllm_ensure_dyn_lds(&attn_fwd8_kernel<D, CAUSAL>, LDS, lds_ok);
-    dim3 grid((P.Sq + 255) / 256, P.H, P.B);
+    const dim3 grid(attn_grid((P.Sq + 255) / 256, P.H, P.B));
     hipLaunchKernelGGL((attn_fwd8_kernel<D, CAUSAL>), grid, dim3(512), LDS, stream, P);
     return dllm_check_launch();
 }
@@ -621,7 +604,7 @@ int launch_fwd(const AttnParams& P, hipStream_t stream) {
     constexpr int LDS = 2 * 2 * 64 * D * 2;
     static std::atomic<uint64_t> lds_ok{0};
     dllm_ensure_dyn_lds(&attn_fwd_kernel<D, CAUSAL, ABL>, LDS, lds_ok);
-    dim3 grid((P.Sq + 127) / 128, P.H, P.B);
+    const dim3 grid(attn_grid((P.Sq + 127) / 128, P.H, P.B));
     hipLaunchKernelGGL((attn_fwd_kernel<D, CAUSAL, ABL>), grid, dim3(256), LDS, stream, P);
     return dllm_check_launch();
 }

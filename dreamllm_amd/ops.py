@@ -54,8 +54,8 @@ SPLITK = True  # split-K for small grids with deep reductions (see dllm_gemm_spl
 GEMM_VARIANT = 0
 
 
-# Attention forward kernel choice handed to dllm_attn_fwd in bits 1-2 of `causal` (include/dreamllm_hip.h): 0 automatic, 1 the
-# 4-wave 128-query kernel, 2 the 8-wave pipelined 256-query kernel.  Tests run every shape through both.
+# Attention kernel choice handed to dllm_attn_fwd / dllm_attn_bwd in bits 1-2 of `causal` (include/dreamllm_hip.h): 0 automatic,
+# 1 the 4-wave kernels, 2 the 8-wave pipelined 256-row kernels.  Tests run every shape through both.
 ATTN_VARIANT = 0
 
 
@@ -297,11 +297,11 @@ def attn_bwd(dout, q, k, v, o, lse, causal, scale=None, seqlens=None, dq=None, d
         dv = torch.empty(B, Sk, Hkv, D, dtype=q.dtype, device=q.device)
     if dk.stride() != dv.stride():
         raise ValueError("dk and dv must share strides")
-    delta = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device)
+    delta = torch.empty(3, B, H, Sq, dtype=torch.float32, device=q.device)  # workspace planes: delta, -delta, -lse/scale
     check("dllm_attn_bwd", _p(dout), _p(q), _p(k), _p(v), _p(o), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(seqlens),
           _p(seqstart), B, H, Hkv, Sq, Sk, D, q.stride(0), q.stride(1), q.stride(2), k.stride(0), k.stride(1), k.stride(2),
           o.stride(0), o.stride(1), o.stride(2), dq.stride(0), dq.stride(1), dq.stride(2), dk.stride(0), dk.stride(1),
-          dk.stride(2), float(scale), int(causal), _stream())
+          dk.stride(2), float(scale), int(bool(causal)) | (ATTN_VARIANT << 1), _stream())
     return dq, dk, dv
 
 

@@ -110,7 +110,8 @@ int dllm_sumpool2_nhwc(const void* in, void* out, int NB, int H, int W, int C, v
 int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, const int* seqstart, int B,
                   int H, int Hkv, int Sq, int Sk, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
                   int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale, int causal, void* stream);
-/* its autograd: dq/dk/dv (dk,dv share strides; may alias slices of one packed dQKV buffer); delta fp32 [B,H,Sq] ws. */
+/* its autograd: dq/dk/dv (dk,dv share strides; may alias slices of one packed dQKV buffer); delta: fp32 [3,B,H,Sq] workspace
+   (planes delta, -delta, -lse/scale).  Bits 1-2 of `causal` select the kernels as in dllm_attn_fwd. */
 int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* o, const float* lse, float* delta,
                   void* dq, void* dk, void* dv, const int* seqlens, const int* seqstart, int B, int H, int Hkv, int Sq, int Sk, int D,
                   int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,

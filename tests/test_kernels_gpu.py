@@ -256,9 +256,9 @@ def attn_ref(q, k, v, causal, seqlen=None):
     return o.transpose(1, 2), lse
 
 
-@pytest.fixture(params=[1, 2], ids=["fwd4wave", "fwd8wave"])
+@pytest.fixture(params=[1, 2], ids=["4wave", "8wave"])
 def attn_variant(request):
-    """every forward-attention test runs on both kernels (4-wave 128-query blocks / 8-wave pipelined 256-query blocks)"""
+    """every attention test runs on both kernel families (4-wave blocks / 8-wave pipelined 256-row blocks)"""
     from dreamllm_amd import ops
     ops.ATTN_VARIANT = request.param
     yield request.param
@@ -472,8 +472,12 @@ def test_linear_autograd_and_lm_head_ce(V):
     (1, 4, 2, 160, 160, 128, True),
     (1, 2, 2, 64, 200, 64, False),
     (1, 2, 1, 200, 200, 64, True),
+    (1, 2, 2, 777, 777, 128, True),    # several 256-row blocks, ragged tail
+    (2, 2, 1, 513, 513, 64, True),     # GQA over 256-key blocks
+    (1, 2, 2, 40, 600, 128, True),     # few queries at the end of a long key axis
+    (1, 1, 1, 1024, 1024, 64, False),
 ])
-def test_attn_bwd(B, H, Hkv, Sq, Sk, D, causal):
+def test_attn_bwd(B, H, Hkv, Sq, Sk, D, causal, attn_variant):
     """dQ/dK/dV against fp32 autograd of the oracle attention.  Bound 1.5e-2: P and dS enter the MFMAs as bf16."""
     ops = _ops()
     torch.manual_seed(Sq * 7 + Sk + D)
@@ -489,7 +493,7 @@ def test_attn_bwd(B, H, Hkv, Sq, Sk, D, causal):
     assert rel_l2(dv, vr.grad) < 1.5e-2
 
 
-def test_attn_bwd_padding_and_strided():
+def test_attn_bwd_padding_and_strided(attn_variant):
     ops = _ops()
     torch.manual_seed(21)
     B, S, H, D = 2, 200, 2, 128

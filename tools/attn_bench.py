@@ -38,6 +38,12 @@ for name, B, Sq, Sk, H, D, causal in shapes:
             res.setdefault(var, []).append(timed(lambda: ops.attn_fwd(q, k, v, causal)))
     ops.ATTN_VARIANT = 0
     o, lse = ops.attn_fwd(q, k, v, causal)
-    tb = timed(lambda: ops.attn_bwd(do, q, k, v, o, lse, causal))
+    resb = {}
+    for rnd in range(2):
+        for var in (1, 2):
+            ops.ATTN_VARIANT = var
+            resb.setdefault(var, []).append(timed(lambda: ops.attn_bwd(do, q, k, v, o, lse, causal)))
+    ops.ATTN_VARIANT = 0
     line = f"{name:26s} " + "  ".join(f"fwd[v{var}] {min(ts):7.3f} ms {flops / min(ts) / 1e9:6.0f} TF" for var, ts in res.items())
-    print(line + f"   bwd {tb:7.3f} ms {2.5 * flops / tb / 1e9:6.0f} TF(alg)", flush=True)
+    line += "  " + "  ".join(f"bwd[v{var}] {min(ts):7.3f} ms {2.5 * flops / min(ts) / 1e9:6.0f} TF(alg)" for var, ts in resb.items())
+    print(line, flush=True)
