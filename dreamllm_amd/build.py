@@ -23,6 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "
 # DREAMLLM_HIP_LIB=.../libdreamllm_hip_bench.so.  The shipped library never contains them.
 if BENCH:
     FLAGS.append("-DDLLM_BENCH_MODES")
+    FLAGS += os.environ.get("DLLM_EXTRA_FLAGS", "").split()  # experiment switches, bench library only
 
 
 def _sources():

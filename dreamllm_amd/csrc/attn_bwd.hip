@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, t = lane & 15;
     const int nqb = (P.Sq + BQ - 1) / BQ;
-    const AttnBlock bm = attn_block_map(nqb, P.H, P.B);
+    const AttnBlock bm = attn_block_map<false>(nqb, P.H, P.B);
     if (!bm.valid) return;
     const int b = bm.b, h = bm.h;
     const int qblk = CAUSAL ? (nqb - 1 - bm.r) : bm.r;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams P) {
 // image (attn_common.h: K is read as row fragments for S^T = K Q^T and as column fragments for dQ^T += K^T dS^T), every LDS read
 // inline asm, requested PRE fragments ahead and retired by counted lgkmcnt.  A 32-query wave tile halves the LDS bytes per MFMA
 // of the 16-query 4-wave kernel above, which at head_dim 128 is LDS-bandwidth bound at half the matrix rate.
-// One tile = 6 segments of 2*DS fragment steps: {K,V row frags of key tile kt -> S^T[kt], dP^T[kt]} for kt = 0..3, then
+// One tile = 6 segments of 2*DS fragment steps: {K,V row frags (alternating) of key tile kt -> S^T[kt], dP^T[kt]} for kt = 0..3, then
 // {K col frags -> dQ^T} for the two 32-key halves.  The softmax algebra of key tile kt (exp2, * (dP - delta), bf16 pack) is
 // spread over the steps of the NEXT segment, i.e. under MFMAs that do not depend on it; delta is folded into the dP
 // accumulator's initial value.
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, t = lane & 15;
     const int nqb = (P.Sq + BQ - 1) / BQ;
-    const AttnBlock bm = attn_block_map(nqb, P.H, P.B);
+    const AttnBlock bm = attn_block_map<CAUSAL>(nqb, P.H, P.B);
     if (!bm.valid) return;
     const int b = bm.b, h = bm.h;
     const int qblk = CAUSAL ? (nqb - 1 - bm.r) : bm.r;
@@ -380,9 +380,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
     auto issue = [&ring, &rlo, &rhi, &raddr, &caddr, cswz](auto fc) {
         constexpr int f = decltype(fc)::value;
         constexpr int seg = f / NS, i = f % NS;
-        if constexpr (seg < 4) {  // K (i < DS) or V row fragment of key tile seg, d step i % DS
-            constexpr int off = seg * 16 * PITCH + (i < DS ? 0 : 2 * TILE);
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % RING]) : "v"(raddr[i % DS]), "n"(off));
+        if constexpr (seg < 4) {  // K (even i) or V row fragment of key tile seg, d step i / 2: four accumulator chains in rotation
+            constexpr int off = seg * 16 * PITCH + ((i & 1) == 0 ? 0 : 2 * TILE);
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % RING]) : "v"(raddr[i >> 1]), "n"(off));
         } else {                  // K column fragment of d tile i, keys of half seg - 4
             constexpr int ks = seg - 4;
             const uint32_t a = caddr + ((uint32_t)(i << 5) ^ cswz);
@@ -468,10 +468,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
                     const bf16x8 a = __builtin_bit_cast(bf16x8, ring[st % RING]);
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
-                        if constexpr (i < DS)
-                            s[seg & 1][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[qt][i % DS], s[seg & 1][qt], 0, 0, 0);
+                        if constexpr ((i & 1) == 0)
+                            s[seg & 1][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[qt][i >> 1], s[seg & 1][qt], 0, 0, 0);
                         else
-                            dp[seg & 1][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dof[qt][i % DS], dp[seg & 1][qt], 0, 0, 0);
+                            dp[seg & 1][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dof[qt][i >> 1], dp[seg & 1][qt], 0, 0, 0);
                     }
                 } else {
                     constexpr int ks = seg - 4;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams P) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, t = lane & 15;
-    const AttnBlock bm = attn_block_map((P.Sk + BKEYS - 1) / BKEYS, P.Hkv, P.B);  // key block 0 sees the most queries: heavy first
+    const AttnBlock bm = attn_block_map<false>((P.Sk + BKEYS - 1) / BKEYS, P.Hkv, P.B);  // key block 0 sees the most queries: heavy first
     if (!bm.valid) return;
     const int b = bm.b, hk = bm.h;
     const int group = P.H / P.Hkv;
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv8_kernel(AttnParams P) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, t = lane & 15;
-    const AttnBlock bm = attn_block_map((P.Sk + BKEYS - 1) / BKEYS, P.Hkv, P.B);  // key block 0 sees the most queries: heavy first
+    const AttnBlock bm = attn_block_map<CAUSAL>((P.Sk + BKEYS - 1) / BKEYS, P.Hkv, P.B);  // key block 0 sees the most queries: heavy first
     if (!bm.valid) return;
     const int b = bm.b, hk = bm.h;
     const int group = P.H / P.Hkv;
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv8_kernel(AttnParams P) {
 }
 
 template <int D, bool CAUSAL>
-int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide) {
+int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_dkv) {
     constexpr int QT = (D == 128) ? 1 : 2;
     constexpr int KT = (D == 128) ? 1 : 2;
     constexpr int LDS_DQ = 2 * 2 * 64 * D * 2;
@@ -1033,14 +1033,14 @@ int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide) {
     const int64_t nthreads = rows * (D / 8);
     hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, P);
     constexpr int BQ = 4 * QT * 16, BKEYS = 4 * KT * 16;
-    if (wide) {
+    if (wide_dq) {
         dllm_ensure_dyn_lds(&attn_bwd_dq8_kernel<D, CAUSAL>, LDS_DQ, lds3_ok);
         hipLaunchKernelGGL((attn_bwd_dq8_kernel<D, CAUSAL>), dim3(attn_grid((P.Sq + 255) / 256, P.H, P.B)), dim3(512), LDS_DQ, stream, P);
     } else {
         dllm_ensure_dyn_lds(&attn_bwd_dq_kernel<D, CAUSAL, QT>, LDS_DQ, lds_ok);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL, QT>), dim3(attn_grid((P.Sq + BQ - 1) / BQ, P.H, P.B)), dim3(256), LDS_DQ, stream, P);
     }
-    if (wide) {
+    if (wide_dkv) {
         constexpr int LDS_DKV8 = 2 * (2 * 64 * D * 2) + 1024;
         static_assert(((2 * 64 * D * 2) & (2 * 64 * D * 2 - 1)) == 0, "buffer toggling by XOR");
         const dim3 grid8(attn_grid((P.Sk + 255) / 256, P.Hkv, P.B));
@@ -1094,9 +1094,11 @@ int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v,
     const int force = causal >> 1;
     causal &= 1;
     P.causal = causal;
-    const bool wide = force == 2 || (force == 0 && Sq >= 512);
-    if (D == 128) return causal ? launch_bwd<128, true>(P, s, wide) : launch_bwd<128, false>(P, s, wide);
-    return causal ? launch_bwd<64, true>(P, s, wide) : launch_bwd<64, false>(P, s, wide);
+    // automatic: the 256-row kernels where the row axis they tile is long enough to fill their blocks (UNet cross-attention has
+    // Sq = 4096 queries over Sk = 64 dream tokens: wide dQ, 4-wave dK/dV)
+    const bool wq = force == 2 || (force == 0 && Sq >= 512), wk = force == 2 || (force == 0 && Sk >= 512);
+    if (D == 128) return causal ? launch_bwd<128, true>(P, s, wq, wk) : launch_bwd<128, false>(P, s, wq, wk);
+    return causal ? launch_bwd<64, true>(P, s, wq, wk) : launch_bwd<64, false>(P, s, wq, wk);
 }
 
 }  // extern "C"

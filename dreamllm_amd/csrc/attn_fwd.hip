@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams P) {
     const int g = lane >> 4, t = lane & 15;
     constexpr int BQ_ = (4 * 2) * 16;
     const int nqb = (P.Sq + BQ_ - 1) / BQ_;
-    const AttnBlock bm = attn_block_map(nqb, P.H, P.B);
+    const AttnBlock bm = attn_block_map<false>(nqb, P.H, P.B);
     if (!bm.valid) return;
     const int b = bm.b, h = bm.h;
     const int qblk = CAUSAL ? (nqb - 1 - bm.r) : bm.r;  // heavy causal blocks first
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
     const int g = lane >> 4, t = lane & 15;
     constexpr int BQ_ = (8 * 2) * 16;
     const int nqb = (P.Sq + BQ_ - 1) / BQ_;
-    const AttnBlock bm = attn_block_map(nqb, P.H, P.B);
+    const AttnBlock bm = attn_block_map<CAUSAL>(nqb, P.H, P.B);
     if (!bm.valid) return;
     const int b = bm.b, h = bm.h;
     const int qblk = CAUSAL ? (nqb - 1 - bm.r) : bm.r;  // heavy causal blocks first
