@@ -97,7 +97,7 @@ def config3(out, a):
     torch.manual_seed(0)
     head = StableDiffusionHead("sd21-base", embed_hidden_size=4096).to("cuda", BF).eval()
     steps = 50
-    for Bi in (1, 8):
+    for Bi in [int(x) for x in a.denoise_batches.split(',')]:
         g = torch.Generator().manual_seed(42)
         pe = (torch.randn(Bi, 64, 4096, generator=g) * 0.02).to("cuda", BF)
         ne = (torch.randn(Bi, 64, 4096, generator=g) * 0.02).to("cuda", BF)
@@ -171,6 +171,7 @@ def _parser():
     ap.add_argument("--sdxl-seq-len", type=int, default=256)
     ap.add_argument("--sdxl-px", type=int, default=1024)
     ap.add_argument("--sdxl-denoise-steps", type=int, default=20)
+    ap.add_argument("--denoise-batches", default="1,8", help="config 3: images per denoise loop (UNet batch = 2x)")
     return ap
 
 
