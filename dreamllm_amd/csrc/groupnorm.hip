@@ -154,6 +154,72 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
     }
 }
 
+// Small problems (the UNet at batch 2 inside the denoise loop: 0.3 - 16 MB per tensor, L2 / MALL resident): ONE launch, one block
+// per (image, group).  Thread (r, j) owns channel pair j of the group and pixels r, r + R, ...: 4-byte loads (a group is C/G
+// channels = 20 - 160 contiguous bytes per pixel), no division in the loops; pass 1 sum / sum of squares, block reduce, pass 2
+// re-reads the slice (it is in the XCD's L2) and writes y.  Replaces partial + finalize + apply (3 launches, ~20 us) by ~6 us
+// where launch count, not bandwidth, is the cost.
+__global__ __launch_bounds__(1024) void gn_small_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gamma,
+                                                        const bf16* __restrict__ beta, bf16* __restrict__ y, float* __restrict__ mean_o,
+                                                        float* __restrict__ rstd_o, int HW, int C, int G, float eps, int act) {
+    __shared__ float red[32];
+    const int n = blockIdx.x / G, g = blockIdx.x % G;
+    const int cpg = C / G, pp = cpg >> 1;
+    const int R = 1024 / pp;
+    const int r = threadIdx.x / pp, j = threadIdx.x - r * pp;
+    const bool live = r < R;
+    const int64_t base = (int64_t)n * HW * C + g * cpg + 2 * j;
+    const int64_t stride = (int64_t)R * C;
+    float s1 = 0.f, s2 = 0.f;
+    if (live) {
+        const bf16* px = x + base + (int64_t)r * C;
+        int p = r;
+        for (; p + 3 * R < HW; p += 4 * R, px += 4 * stride) {  // four independent loads in flight per thread
+            const bf16x2 v0 = *reinterpret_cast<const bf16x2*>(px), v1 = *reinterpret_cast<const bf16x2*>(px + stride);
+            const bf16x2 v2 = *reinterpret_cast<const bf16x2*>(px + 2 * stride), v3 = *reinterpret_cast<const bf16x2*>(px + 3 * stride);
+            const float a0 = (float)v0[0], b0 = (float)v0[1], a1 = (float)v1[0], b1 = (float)v1[1];
+            const float a2 = (float)v2[0], b2 = (float)v2[1], a3 = (float)v3[0], b3 = (float)v3[1];
+            s1 += (a0 + b0) + (a1 + b1) + (a2 + b2) + (a3 + b3);
+            s2 += (a0 * a0 + b0 * b0) + (a1 * a1 + b1 * b1) + (a2 * a2 + b2 * b2) + (a3 * a3 + b3 * b3);
+        }
+        for (; p < HW; p += R, px += stride) {
+            const bf16x2 v = *reinterpret_cast<const bf16x2*>(px);
+            const float a = (float)v[0], b = (float)v[1];
+            s1 += a + b;
+            s2 += a * a + b * b;
+        }
+    }
+    s1 = block_sum<16>(s1, red);
+    s2 = block_sum<16>(s2, red + 16);
+    const float cnt = (float)HW * (float)cpg;
+    const float mean = s1 / cnt;
+    const float rstd = rsqrtf(fmaxf(s2 / cnt - mean * mean, 0.f) + eps);
+    if (threadIdx.x == 0) {
+        mean_o[n * G + g] = mean;
+        rstd_o[n * G + g] = rstd;
+    }
+    if (live) {
+        const int c = g * cpg + 2 * j;
+        const float a0 = rstd * (float)gamma[c], a1 = rstd * (float)gamma[c + 1];
+        const float b0 = (float)beta[c] - mean * a0, b1 = (float)beta[c + 1] - mean * a1;
+        const bf16* px = x + base + (int64_t)r * C;
+        bf16* py = y + base + (int64_t)r * C;
+#pragma unroll 4
+        for (int p = r; p < HW; p += R, px += stride, py += stride) {
+            const bf16x2 v = *reinterpret_cast<const bf16x2*>(px);
+            float z0 = (float)v[0] * a0 + b0, z1 = (float)v[1] * a1 + b1;
+            if (act) {
+                z0 = silu_f(z0);
+                z1 = silu_f(z1);
+            }
+            bf16x2 o;
+            o[0] = (bf16)z0;
+            o[1] = (bf16)z1;
+            *reinterpret_cast<bf16x2*>(py) = o;
+        }
+    }
+}
+
 // dx = rstd * (dxhat - c1 - xhat * c2)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -249,6 +315,12 @@ int dllm_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void*
     const int R = gn_geometry(HW, C, NB, &block, &nchunks, &ppc);
     if (R < 0) return DLLM_ERR_SHAPE;
     hipStream_t s = (hipStream_t)stream;
+    const int cpg = C / G;
+    if ((int64_t)NB * HW * C <= ((int64_t)1 << 23) && (cpg & 1) == 0 && cpg <= 512) {  // small: one launch (see gn_small_kernel)
+        hipLaunchKernelGGL(gn_small_kernel, dim3(NB * G), dim3(1024), 0, s, (const bf16*)x, (const bf16*)gamma, (const bf16*)beta,
+                           (bf16*)y, mean, rstd, HW, C, G, eps, act);
+        return dllm_check_launch();
+    }
     const size_t lds = (size_t)block * 16 * sizeof(float);
     hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunks, NB), dim3(block), lds, s, (const bf16*)x, nullptr, nullptr, nullptr,
                        nullptr, nullptr, part, HW, C, G, ppc, 0);
