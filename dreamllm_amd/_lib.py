@@ -25,8 +25,8 @@ SIGNATURES = {
     "dllm_layernorm_bwd": [c_void_p] * 10 + [c_int, c_i64, c_int, c_void_p],
     "dllm_gemm_bf16": [c_void_p] * 5 + [c_i64] * 7 + [c_int] * 5 + [c_float, c_void_p],
     "dllm_gemm_splitk_hint": [c_i64, c_i64, c_i64],
-    "dllm_gemm_bf16_splitk": [c_void_p] * 5 + [c_i64] * 7 + [c_int] * 5 + [c_float, c_int, c_void_p, c_int, c_void_p],
-    "dllm_conv2d_nhwc_bf16_splitk": [c_void_p] * 6 + [c_int] * 15 + [c_int, c_void_p, c_int, c_void_p],
+    "dllm_gemm_bf16_splitk": [c_void_p] * 5 + [c_i64] * 7 + [c_int] * 5 + [c_float, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "dllm_conv2d_nhwc_bf16_splitk": [c_void_p] * 6 + [c_int] * 15 + [c_int, c_void_p, c_void_p, c_int, c_void_p],
     "dllm_conv2d_nhwc_bf16": [c_void_p] * 6 + [c_int] * 15 + [c_void_p],
     "dllm_groupnorm_fwd": [c_void_p] * 8 + [c_int] * 4 + [c_float, c_int, c_void_p],
     "dllm_groupnorm_bwd": [c_void_p] * 10 + [c_int] * 5 + [c_void_p],

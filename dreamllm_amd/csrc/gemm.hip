@@ -84,6 +84,7 @@ struct GemmParams {
     int dbg_noload;  // benchmark-only: skip the K-loop prefetches (wrong results) to expose the compute+barrier ceiling
     int splitk;      // > 1: blockIdx.y owns a K range and writes raw fp32 partials to ws[split][M][N]
     float* ws;
+    int* counters;   // split-K: one arrival counter per output tile (zero on entry, left zero): the last K slice reduces in-kernel
     ConvGeom cv;
 };
 
@@ -329,9 +330,87 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& P, int64_t m, 
 // ---- epilogue shared by the kernels: lane holds C[m][n..n+3], m = mbase+i*16+(lane&15), n = nbase+j*16+(lane>>4)*4
 template <int MI>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[MI][4], int64_t mbase, int64_t nbase, int lane,
-                                              int split = 0) {
+                                              int split = 0, int tile = 0, int* lds_flag = nullptr) {
     const bool vec_ok = ((P.N & 3) == 0) && ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
     if (P.dbg_noload == 3 && acc[0][0][0] != 12345.678f) return;  // benchmark-only: no C stores (the test keeps acc live)
+    if (P.splitk > 1) {
+        // raw fp32 partial slab of this K slice (N % 4 == 0 enforced by the host)
+        const bool fused = P.counters != nullptr && lds_flag != nullptr;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int64_t m = mbase + i * 16 + (lane & 15);
+            if (m >= P.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t n = nbase + j * 16 + (lane >> 4) * 4;
+                if (n >= P.N) continue;
+                float* dst = P.ws + ((int64_t)split * P.M + m) * P.N + n;
+                if (fused)  // write-through (sc1): the slab is visible at agent scope without a whole-L2 write-back
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[i][j]) : "memory");
+                else
+                    *reinterpret_cast<f32x4*>(dst) = acc[i][j];
+            }
+        }
+        if (!fused) return;  // the separate reduce kernel follows
+        // In-kernel reduction: every K slice of a tile publishes its slab with write-through stores (the other slices run on other
+        // XCDs, whose L2s are not coherent with this one; a release fence = whole-L2 write-back per block measured 1.5x SLOWER than
+        // the separate reduce kernel) and takes a ticket once all its stores have completed; the slice that draws the last ticket
+        // invalidates (agent-scope acquire), sums the slabs in slice order (deterministic: the order of splitk_reduce_kernel) and
+        // applies the epilogue.  One launch less per split GEMM: ~140 per denoising step of the UNet at batch 2.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            *lds_flag = __hip_atomic_fetch_add(P.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*lds_flag != P.splitk - 1) return;
+        if (threadIdx.x == 0) __hip_atomic_store(P.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the slabs are read with agent-coherent loads (sc0 sc1: they miss this XCD's caches) instead of an acquire fence: a
+        // buffer_inv per reducing block empties the XCD's L2 under every other block of the launch (measured 109 -> 75 steps/s).
+        // All loads of one slice are in flight together (MI * 4 requests per lane), slices are summed in order.
+        f32x4 sum[MI][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int z = 0; z < P.splitk; ++z) {
+            f32x4 t[MI][4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int64_t m = min(mbase + i * 16 + (lane & 15), P.M - 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t n = min(nbase + j * 16 + (lane >> 4) * 4, P.N - 4);
+                    const float* src = P.ws + ((int64_t)z * P.M + m) * P.N + n;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(t[i][j]) : "v"(src) : "memory");
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (i == 0 && j == 0)
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]) : : "memory");
+                    else
+                        asm volatile("" : "+v"(t[i][j]));
+                    sum[i][j] += t[i][j];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int64_t m = mbase + i * 16 + (lane & 15);
+            if (m >= P.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t n = nbase + j * 16 + (lane >> 4) * 4;
+                if (n >= P.N) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = sum[i][j][r] * P.alpha;
+                epilogue_store4(P, m, n, v, vec_ok);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int64_t m = mbase + i * 16 + (lane & 15);
@@ -340,10 +419,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
         for (int j = 0; j < 4; ++j) {
             const int64_t n = nbase + j * 16 + (lane >> 4) * 4;
             if (n >= P.N) continue;
-            if (P.splitk > 1) {  // raw fp32 partial; the reduce kernel applies the epilogue (N % 4 == 0 enforced by the host)
-                *reinterpret_cast<f32x4*>(P.ws + ((int64_t)split * P.M + m) * P.N + n) = acc[i][j];
-                continue;
-            }
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * P.alpha;
@@ -580,7 +655,7 @@ __global__ __launch_bounds__(2 * T, 2) void gemm_bf16_kernel(GemmParams P) {
     if (epilogue_lds_ok(P, m0, n0, T))  // the loop ended on a barrier: the stages are free to serve as per-wave staging regions
         gemm_epilogue_lds<MI>(P, acc, smem + wave * 8192, m0 + wm, n0 + wn, lane);
     else
-        gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane, blockIdx.y);
+        gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane, blockIdx.y, pid_m * num_pid_n + pid_n, reinterpret_cast<int*>(smem));
 }
 
 
@@ -1036,7 +1111,7 @@ int launch_gemm_t(const GemmParams& P, hipStream_t stream) {
     dllm_ensure_dyn_lds(&gemm_bf16_kernel<AL, BL, T>, LDS, lds_ok);
     const int sk = P.splitk > 1 ? P.splitk : 1;
     hipLaunchKernelGGL((gemm_bf16_kernel<AL, BL, T>), dim3((unsigned)tiles, sk), dim3(2 * T), LDS, stream, P);
-    if (sk > 1) {
+    if (sk > 1 && P.counters == nullptr) {
         int64_t work = P.M * (P.N >> 2);
         int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, P);
@@ -1104,19 +1179,23 @@ extern "C" {
 // epi: 0 none, 1 exact-erf GELU, 2 quick-GELU, 3 SiLU.  out_dtype: DLLM_BF16 / DLLM_F32.
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
-                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int variant, void* stream);
+                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int* counters, int variant,
+                          void* stream);
 
 int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
                    int out_dtype, int accumulate, float alpha, void* stream) {
     return dllm_gemm_bf16_splitk(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, ldr, layout_a, layout_b, epi, out_dtype,
-                                 accumulate, alpha, 1, nullptr, 0, stream);
+                                 accumulate, alpha, 1, nullptr, nullptr, 0, stream);
 }
 
-// splitk > 1: workspace = fp32 [splitk][M][N] (caller-allocated); requires N % 4 == 0.
+// splitk > 1: workspace = fp32 [splitk][M][N] (caller-allocated); requires N % 4 == 0.  counters: optional int32[>= number of
+// 128 x 128 output tiles], all zero on entry and left all zero: the reduction then happens inside the GEMM launch (the last K
+// slice of a tile to arrive reduces it); NULL = a separate reduce kernel.  One counter array per stream in flight.
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
-                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int variant, void* stream) {
+                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int* counters, int variant,
+                          void* stream) {
     Variant V;
     if (parse_variant(variant, V) != DLLM_OK) return DLLM_ERR_SHAPE;
     if (splitk > 1 && (workspace == nullptr || (N & 3))) return DLLM_ERR_SHAPE;
@@ -1133,7 +1212,7 @@ int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bia
     P.A = (const bf16*)A; P.B = (const bf16*)B; P.C = C; P.bias = (const bf16*)bias; P.residual = (const bf16*)residual;
     P.M = M; P.N = N; P.K = K; P.lda = lda; P.ldb = ldb; P.ldc = ldc; P.ldr = ldr;
     P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = accumulate; P.alpha = alpha;
-    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.dbg_noload = V.dbg_noload;
+    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.counters = splitk > 1 ? counters : nullptr; P.dbg_noload = V.dbg_noload;
     // grouped tile order: M rows per column group.  Measured (tools/gemm_groupm_sweep.py): 2-4 is 2-5 % faster than 8 for the
     // forward / input-gradient layouts (A = activations, M = 32768), 8 is best for the weight gradient; 16+ loses 10 %.
     P.group_m = V.group_m > 0 ? V.group_m : (layout_a == A_M ? 8 : 4);
@@ -1151,8 +1230,10 @@ int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || (N & 3)) return 1;
     const int64_t tiles = cdiv64(M, 128) * cdiv64(N, 128);
     const int64_t ktiles = cdiv64(K, BK);
-    if (tiles >= 128 || ktiles < 16) return 1;
-    int64_t want = cdiv64(384, tiles);          // aim at ~1.5 blocks per CU
+    if (tiles > 256 || ktiles < 16) return 1;
+    // aim at ~1.5 blocks per CU for tiny grids; grids of 128..256 tiles (one 128-tile block on half to all of the CUs, e.g. the
+    // 192-tile 3x3 convs of the UNet's first level at batch 2) are split so that two blocks share a CU: 512 slots / tiles
+    int64_t want = tiles >= 128 ? 512 / tiles : cdiv64(384, tiles);
     int64_t maxs = ktiles / 8;                  // keep >= 8 K tiles (512 k) per split
     int64_t s = want < maxs ? want : maxs;
     if (s > 32) s = 32;
@@ -1167,20 +1248,20 @@ int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K) {
 int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
                                  const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                                  int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,
-                                 float* workspace, int variant, void* stream);
+                                 float* workspace, int* counters, int variant, void* stream);
 
 int dllm_conv2d_nhwc_bf16(const void* x, const void* w, void* out, const void* bias, const void* residual,
                           const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                           int stride, int pad, int up2, int even_only, int epi, int out_dtype, void* stream) {
     return dllm_conv2d_nhwc_bf16_splitk(x, w, out, bias, residual, image_bias, NB, H, W, C, OH, OW, CO, KH, KW, stride, pad, up2,
-                                        even_only, epi, out_dtype, 1, nullptr, 0, stream);
+                                        even_only, epi, out_dtype, 1, nullptr, nullptr, 0, stream);
 }
 
-// splitk > 1: workspace = fp32 [splitk][NB*OH*OW][CO]; requires CO % 4 == 0.
+// splitk > 1: workspace = fp32 [splitk][NB*OH*OW][CO]; requires CO % 4 == 0; counters as in dllm_gemm_bf16_splitk.
 int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
                                  const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                                  int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,
-                                 float* workspace, int variant, void* stream) {
+                                 float* workspace, int* counters, int variant, void* stream) {
     Variant V;
     if (parse_variant(variant, V) != DLLM_OK) return DLLM_ERR_SHAPE;
     if (splitk > 1 && (workspace == nullptr || (CO & 3))) return DLLM_ERR_SHAPE;
@@ -1195,7 +1276,7 @@ int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const 
     P.lda = C; P.ldb = P.K; P.ldc = CO; P.ldr = CO;
     P.epi = epi; P.out_f32 = (out_dtype == DLLM_F32); P.accumulate = 0; P.alpha = 1.0f;
     P.rg_bias = (const bf16*)image_bias; P.rg_rows = (int64_t)OH * OW;
-    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.dbg_noload = V.dbg_noload;
+    P.splitk = splitk > 1 ? splitk : 1; P.ws = workspace; P.counters = splitk > 1 ? counters : nullptr; P.dbg_noload = V.dbg_noload;
     P.group_m = V.group_m > 0 ? V.group_m : 4;  // output pixels are the M dimension (activations), as in the forward GEMMs
     P.cv = ConvGeom{H, W, C, OH, OW, KH, KW, stride, pad, up2, even_only};
     return launch_gemm<A_CONV, B_K>(P, V, (hipStream_t)stream);

@@ -48,6 +48,21 @@ def _bf16(*ts):
 EPI = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3}
 
 SPLITK = True  # split-K for small grids with deep reductions (see dllm_gemm_splitk_hint)
+# Opt-in: the last K slice of a tile reduces inside the GEMM launch (no separate reduce kernel).  Correct and bit-identical to the
+# reduce kernel (tests), but SLOWER on MI355X: the slices of a tile run on different XCDs, so the slabs must be written through
+# and read around the non-coherent L2s (109 -> 85 denoise steps/s; with release / acquire fences 72).  The reduce kernel stays.
+SPLITK_FUSED_REDUCE = False
+_SPLITK_COUNTERS = {}
+
+
+def _splitk_counters(device):
+    """Arrival counters of the in-kernel split-K reduction: int32[16384] per (device, stream), zero at rest (the kernels leave
+    them zero).  Allocated once, outside any stream capture when the first split GEMM runs before the capture (warm-up)."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _SPLITK_COUNTERS.get(key)
+    if buf is None:
+        buf = _SPLITK_COUNTERS[key] = torch.zeros(16384, dtype=torch.int32, device=device)
+    return buf
 
 # Kernel variant handed to every GEMM / conv launch (include/dreamllm_hip.h `variant`): 0 = automatic.  Python-side knob for
 # tests and microbenchmarks (`with ops.gemm_variant(259): ...`); the C library itself keeps no state.
@@ -204,10 +219,11 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
     sk = _lib.call("dllm_gemm_splitk_hint", M, N, K) if SPLITK else 1
     ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
+    cnt = _splitk_counters(a.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-M // 128) * -(-N // 128) <= 16384) else None
     with _GemmTimer(2.0 * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
         check("dllm_gemm_bf16_splitk", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
               ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),
-              sk, _p(ws), GEMM_VARIANT, _stream())
+              sk, _p(ws), _p(cnt), GEMM_VARIANT, _stream())
     return out
 
 
@@ -907,9 +923,10 @@ def conv2d_nhwc(x, w2d, CO, KH, KW, stride=1, pad=1, OH=None, OW=None, bias=None
     Mg = N * OH * OW
     sk = _lib.call("dllm_gemm_splitk_hint", Mg, CO, KH * KW * C) if SPLITK else 1
     ws = torch.empty(sk * Mg * CO, dtype=torch.float32, device=x.device) if sk > 1 else None
+    cnt = _splitk_counters(x.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-Mg // 128) * -(-CO // 128) <= 16384) else None
     with _GemmTimer(2.0 * N * OH * OW * CO * KH * KW * C, "conv"):
         check("dllm_conv2d_nhwc_bf16_splitk", _p(x), _p(w2d), _p(out), _p(bias), _p(residual), _p(image_bias), N, H, W, C, OH,
-              OW, CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), sk, _p(ws), GEMM_VARIANT, _stream())
+              OW, CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), sk, _p(ws), _p(cnt), GEMM_VARIANT, _stream())
     return out
 
 

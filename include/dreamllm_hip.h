@@ -72,7 +72,10 @@ int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, cons
                    int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
                    int out_dtype, int accumulate, float alpha, void* stream);
 /* Split-K variants for small grids with deep reductions (UNet at batch 2): splitk > 1 writes fp32 partials to the caller's
- * workspace [splitk][M][N] and a deterministic reduce kernel applies the epilogue.  dllm_gemm_splitk_hint suggests splitk. */
+ * workspace [splitk][M][N]; the reduction is deterministic (slice order).  `counters` (optional): int32[>= ceil(M/128)*ceil(N/128)],
+ * all zero on entry and left all zero -- the last K slice of a tile to arrive then reduces it INSIDE the GEMM launch (agent-scope
+ * release/acquire around a ticket); NULL = a separate reduce kernel follows.  Use one counter array per stream in flight.
+ * dllm_gemm_splitk_hint suggests splitk. */
 int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K);
 /* `variant` selects the kernel PER CALL (the library holds no mutable state; every entry point is re-entrant and may be called
  * from any thread on any stream): low 16 bits = tile family -- 0 automatic (what the product passes), 128 / 256 register-staged
@@ -82,11 +85,12 @@ int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K);
  * wrong-result diagnostic modes 258 / 260 / 263 / 265 used by tools/; the shipped library does not contain them.) */
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
-                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int variant, void* stream);
+                          int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int* counters, int variant,
+                          void* stream);
 int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
                                  const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                                  int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,
-                                 float* workspace, int variant, void* stream);
+                                 float* workspace, int* counters, int variant, void* stream);
 /* NHWC convolution (3x3 / 1x1) as implicit GEMM: ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D, Upsample2D,
  * conv_in/conv_out of UNet2DConditionModel and AutoencoderKL [ext] (call sites modeling_plugins.py:511,556,815-821,842).
  * x [NB,H,W,C] bf16, w [CO][KH*KW*C] bf16 (k = (kh,kw,ci)), out [NB,OH,OW,CO]; image_bias [NB,CO] = per-image

@@ -553,6 +553,30 @@ def test_gemm_splitk_small_grid(M, N, K):
     assert rel_l2(dx, x.float() @ rnd(K, N, seed=1).float()) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 1280, 11520), (8192, 320, 2880), (2048, 640, 5760), (104, 328, 2048)])
+def test_gemm_splitk_in_kernel_reduction_is_bit_identical(M, N, K):
+    """The in-kernel split-K reduction (last K slice of a tile reduces, agent-scope release / acquire around a ticket) against
+    the separate reduce kernel: same summation order => bit-identical, 40 launches back to back (slices of one tile run on
+    different XCDs: a stale read would show as a mismatch), counters back at zero afterwards."""
+    from dreamllm_amd import _lib
+    ops = _ops()
+    assert _lib.call("dllm_gemm_splitk_hint", M, N, K) > 1
+    torch.manual_seed(M + N)
+    x, w, b, r = rnd(M, K).to(DEV), rnd(N, K, scale=0.02).to(DEV), rnd(N).to(DEV), rnd(M, N).to(DEV)
+    assert ops.SPLITK_FUSED_REDUCE is False  # opt-in (measured slower than the reduce kernel, ops.py)
+    ref = ops.linear_fwd(x, w, bias=b, epi="silu", residual=r)
+    ops.SPLITK_FUSED_REDUCE = True
+    try:
+        for it in range(40):
+            y = ops.linear_fwd(x, w, bias=b, epi="silu", residual=r)
+            assert torch.equal(y, ref), it
+    finally:
+        ops.SPLITK_FUSED_REDUCE = False
+    torch.cuda.synchronize()
+    for buf in ops._SPLITK_COUNTERS.values():
+        assert int(buf.abs().sum()) == 0
+
+
 # ----------------------------------------------------------------------------- greedy-decode kernels
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (1, 11008, 4096), (3, 1000, 11008), (8, 515, 128), (2, 32008, 512)])
 @pytest.mark.parametrize("f32", [False, True])
