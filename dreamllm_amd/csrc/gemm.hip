@@ -40,19 +40,21 @@ struct Variant {
     int glds_pipe = 1;   // software-pipelined direct-to-LDS kernel (default); 0 = plain direct-to-LDS kernel
     int dbg_noload = 0;  // benchmark-only wrong-result modes; compiled in with -DDLLM_BENCH_MODES only
     int group_m = 0;     // 0: per-layout default
+    int force_n128 = 0;  // tile code 262: the 256 x 128 pipelined kernel wherever it is eligible (tests)
 };
 static inline int parse_variant(int variant, Variant& v) {
     const int tile = variant & 0xffff;
     v.group_m = (variant >> 16) & 0xff;
-    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259;
+    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262;
 #ifdef DLLM_BENCH_MODES
     ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265;
     v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
 #endif
     if (!ok || (variant >> 24) != 0) return DLLM_ERR_SHAPE;
     v.use_glds = (tile == 0 || tile >= 257);
-    v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 263 || tile == 265);
+    v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 262 || tile == 263 || tile == 265);
     v.force_tile = tile >= 257 ? 256 : tile;
+    v.force_n128 = tile == 262;
     return DLLM_OK;
 }
 
@@ -434,9 +436,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
 // region in two 64-row halves: ds_write_b64 in the accumulator layout (XOR-swizzled: chunk ^ 2*((row>>1)&7), conflict-free
 // for the 16-lane write groups), ds_read_b128 row-contiguous, then 16-byte global stores of 8 rows x 128 contiguous bytes.
 // Bias / activation / residual / accumulate are applied before the LDS write (single rounding, as in the direct epilogue).
-__device__ __forceinline__ bool epilogue_lds_ok(const GemmParams& P, int64_t m0, int64_t n0, int T) {
+__device__ __forceinline__ bool epilogue_lds_ok(const GemmParams& P, int64_t m0, int64_t n0, int TM, int TN) {
     return !P.out_f32 && P.splitk <= 1 && P.dbg_noload != 3 && (P.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(P.C) & 15) == 0 &&
-           m0 + T <= P.M && n0 + T <= P.N && (P.residual == nullptr || (P.ldr & 3) == 0);
+           m0 + TM <= P.M && n0 + TN <= P.N && (P.residual == nullptr || (P.ldr & 3) == 0);
+}
+__device__ __forceinline__ bool epilogue_lds_ok(const GemmParams& P, int64_t m0, int64_t n0, int T) {
+    return epilogue_lds_ok(P, m0, n0, T, T);
 }
 // bias / per-image bias / activation for 4 consecutive outputs of a full tile
 __device__ __forceinline__ void epilogue_bias_act4(const GemmParams& P, int64_t m, int64_t n, float (&v)[4]) {
@@ -698,6 +703,16 @@ __device__ __forceinline__ void glds_mc_tile(const bf16* base, int64_t ld, int64
     }
 }
 
+// group `grp` (8 rows x 128 B) of a k-contiguous tile, for tiles that are not 4 groups per wave
+__device__ __forceinline__ void glds_kc_grp(const bf16* base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, char* tile,
+                                            int grp, int lane) {
+    const int r = grp * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    int64_t row = row0 + r;
+    row = row < nrows ? row : nrows - 1;
+    GLDS16(base + row * ld + k0 + c * 8, tile + grp * 1024);
+}
+
 // one 1-KiB group (p-th of this wave's four) of the tiles above, for kernels that spread the DMA issue over the k loop
 __device__ __forceinline__ void glds_kc_one(const bf16* base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, char* tile,
                                             int wave, int lane, int p) {
@@ -956,17 +971,22 @@ __device__ __forceinline__ void glds_conv_one(const bf16* x, const ConvGeom& g, 
     GLDS16(src, tile + grp * 1024);
 }
 
-template <int AL, int BL>
+// BN_ = 256: 2 x 4 waves of 128 x 64; BN_ = 128 (k-contiguous B only): 4 x 2 waves of 64 x 64 -- a 256 x 128 block tile for narrow
+// outputs (the 320-channel UNet layers are 3 x 128 = 83 % full instead of 2 x 256 = 62 %), same wave-level stream.
+template <int AL, int BL, int BN_ = 256>
 __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int T = 256, BM = T, BN = T;
-    constexpr int TILE_BYTES = T * BK * 2, STAGE = 2 * TILE_BYTES;
-    constexpr int WC = 4, MI = 8;
+    constexpr int T = 256, BM = T, BN = BN_;
+    static_assert(BN == 256 || (BN == 128 && BL == B_K), "the 128-wide tile reads a k-contiguous B image");
+    constexpr int TILE_BYTES = BM * BK * 2, TILE_B_BYTES = BN * BK * 2, STAGE = TILE_BYTES + TILE_B_BYTES;
+    constexpr int WC = BN / 64, MI = (BM / (8 / WC)) / 16;  // wave grid (8 / WC) x WC, MI 16-row MFMA tiles per wave
+    constexpr int NBD = BN / 64;                            // DMA instructions per wave for the B tile (A: 4)
+    constexpr int NG = 2 * MI;                              // MFMA groups per K tile
     constexpr bool AMC = (AL == A_M), BMC = (BL == B_N);
     constexpr int OA = AMC ? 2 : 1, OB = BMC ? 2 : 1;  // LDS operations per fragment
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave / WC) * (T / 2), wn = (wave % WC) * 64;
+    const int wm = (wave / WC) * (MI * 16), wn = (wave % WC) * 64;
 
     const int num_pid_m = (int)((P.M + BM - 1) / BM), num_pid_n = (int)((P.N + BN - 1) / BN);
     const int nwg = num_pid_m * num_pid_n;
@@ -1006,7 +1026,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) glds_conv_one(P.A, P.cv, cdma, (int)(k0 / P.cv.C), (int)(k0 % P.cv.C), ta, wave, lane, q);
         }
-        if constexpr (BL == B_K)
+        if constexpr (BN == 128) {
+#pragma unroll
+            for (int q = 0; q < NBD; ++q) glds_kc_grp(P.B, P.ldb, n0, P.N, k0, tb, wave * NBD + q, lane);
+        } else if constexpr (BL == B_K)
             glds_kc_tile(P.B, P.ldb, n0, P.N, k0, tb, wave, lane);
         else
             glds_mc_tile(P.B, P.ldb, n0, P.N, k0, tb, wave, lane);
@@ -1039,7 +1062,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
             else
                 glds_conv_one(P.A, P.cv, cdma, ctap, cci, ta, wave, lane, q);
         } else {
-            if constexpr (BL == B_K)
+            if constexpr (BN == 128)
+                glds_kc_grp(P.B, P.ldb, n0, P.N, k0, tb, wave * NBD + (q - 4), lane);
+            else if constexpr (BL == B_K)
                 glds_kc_one(P.B, P.ldb, n0, P.N, k0, tb, wave, lane, q - 4);
             else
                 glds_mc_one(P.B, P.ldb, n0, P.N, k0, tb, wave, lane, q - 4);
@@ -1063,13 +1088,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
                 ++ctap;
             }
         }
-        static_for<0, 16>([&](auto gc) {
-            constexpr int g = decltype(gc)::value, kk = g >> 3, i = g & 7;
-            if constexpr (g < 8) {  // one DMA instruction per group over the first k step: no 64-KiB burst per CU
+        static_for<0, NG>([&](auto gc) {
+            constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
+            if constexpr (g < 4 + NBD) {  // one DMA instruction per group from the start of the tile: no 64-KiB burst per CU
                 if (pf) issue_one(kpf, (t + 1) & 1, g);
             }
-            if constexpr (g < 15) {
-                constexpr int kn = (g + 1) >> 3, in = (g + 1) & 7;
+            if constexpr (g < NG - 1) {
+                constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
                 if constexpr (in == 0)
                     static_for<0, 4>([&](auto j) { fragr_issue<BMC, decltype(j)::value, kn>(fb[kn][decltype(j)::value], bb); });
                 fragr_issue<AMC, in, kn>(fa[(g + 1) & 1], ab);
@@ -1092,7 +1117,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
             __builtin_amdgcn_sched_barrier(0);
         });
     }
-    if (epilogue_lds_ok(P, m0, n0, T)) {
+    if (epilogue_lds_ok(P, m0, n0, BM, BN)) {
         // every wave must be done with its fragment reads before the stages are reused as per-wave staging regions
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -1128,6 +1153,16 @@ static inline double tile_eff(int64_t M, int64_t N, int T, double speed) {
     return ((double)M * N) / ((double)tm * tn * T * T) * ((double)tiles / (double)(rounds * slots)) * speed;
 }
 
+// Three-way choice when the pipelined kernels are eligible: estimated time = rounds x (fixed + K tiles x per-K-tile cost) with the
+// per-round figures measured on the UNet conv shapes (tools/microbench.py --only conv --tile {128,259,262}; microseconds):
+// 256 x 256 pipelined 9 + 1.9 k, 256 x 128 pipelined 6 + 1.3 k (0.69 of the big tile's time for half its outputs), 128 x 128
+// register-staged 6 + 1.75 k with two blocks per CU.  Only grids that fill the chip are compared (smaller ones are split-K or
+// keep the padding-based choice above).
+static inline double tile_cost_us(int64_t M, int64_t N, int64_t K, int TM, int TN, int64_t slots, double fixed, double perk) {
+    const int64_t tiles = cdiv64(M, TM) * cdiv64(N, TN);
+    return (double)cdiv64(tiles, slots) * (fixed + (double)K / 64.0 * perk);
+}
+
 template <int AL, int BL>
 int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     if (P.M <= 0 || P.N <= 0) return DLLM_OK;
@@ -1135,8 +1170,28 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     bool glds_ok = V.use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K);
     if (AL == A_CONV)  // LDS-DMA gather: plain geometry, a K tile inside one tap, pipelined kernel only
         glds_ok = glds_ok && V.glds_pipe && (P.cv.C % BK) == 0 && !P.cv.up_shift && !P.cv.even_only && BL == B_K;
-    const bool pick256 = tile_eff(P.M, P.N, 256, glds_ok ? 1.15 : 1.0) >= tile_eff(P.M, P.N, 128, 0.85);
+    const double e256 = tile_eff(P.M, P.N, 256, glds_ok ? 1.15 : 1.0), e128 = tile_eff(P.M, P.N, 128, 0.85);
+    const bool pick256 = e256 >= e128;
     if (P.splitk > 1) return launch_gemm_t<AL, BL, 128>(P, stream);
+    if constexpr (BL == B_K && (AL == A_K || AL == A_CONV)) {
+        // narrow outputs (N = 320: 62 % of two 256-wide tiles, 83 % of three 128-wide ones): the pipelined kernel on 256 x 128 tiles
+        bool n128 = V.force_n128 != 0;
+        if (!n128 && V.force_tile == 0 && glds_ok && cdiv64(P.M, 256) * cdiv64(P.N, 128) >= 256) {
+            const double c256 = tile_cost_us(P.M, P.N, P.K, 256, 256, 256, 9.0, 1.9);
+            const double cn = tile_cost_us(P.M, P.N, P.K, 256, 128, 256, 6.0, 1.3);
+            const double c128 = tile_cost_us(P.M, P.N, P.K, 128, 128, 512, 6.0, 1.75);
+            n128 = cn < c256 && cn < c128;
+        }
+        if (glds_ok && V.glds_pipe && n128) {
+            constexpr int LDSN = 2 * (256 + 128) * BK * 2;
+            static std::atomic<uint64_t> ldsn_ok{0};
+            dllm_ensure_dyn_lds(&gemm_pipe_kernel<AL, BL, 128>, LDSN, ldsn_ok);
+            const int64_t tiles = cdiv64(P.M, 256) * cdiv64(P.N, 128);
+            if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+            hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL, 128>), dim3((unsigned)tiles), dim3(512), LDSN, stream, P);
+            return dllm_check_launch();
+        }
+    }
     if (V.force_tile == 256 || (V.force_tile == 0 && pick256)) {
         if constexpr (AL == A_CONV) {
             if constexpr (BL == B_K) {

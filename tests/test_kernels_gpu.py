@@ -139,7 +139,7 @@ def test_layernorm_fwd_bwd(rows, D):
 
 
 # ----------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[128, 256, 257, 259])
+@pytest.fixture(params=[128, 256, 257, 259, 262])
 def gemm_tile(request):
     """run the GEMM tests once per block-tile variant (128x128 / 4 waves and 256x256 / 8 waves)"""
     from dreamllm_amd import ops
