@@ -10,10 +10,11 @@ from dreamllm_amd import ops  # noqa: E402
 BF = torch.bfloat16
 T = 32768
 x = torch.randn(T, 4096, device="cuda").to(BF)
-w = (torch.randn(11008, 4096, device="cuda") * 0.02).to(BF)
-dy = torch.randn(T, 11008, device="cuda").to(BF)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 22016   # packed gate|up projection of the decoder layer (round 2); 11008 = one of them
+w = (torch.randn(N, 4096, device="cuda") * 0.02).to(BF)
+dy = torch.randn(T, N, device="cuda").to(BF)
 for _ in range(3):
-    ops.linear_fwd(x, w)       # gate/up forward   [32768 x 11008 x 4096]
+    ops.linear_fwd(x, w)       # gate|up forward   [32768 x N x 4096]
     ops.linear_dgrad(dy, w)    # dgrad
     ops.linear_wgrad(dy, x)    # wgrad
 torch.cuda.synchronize()
