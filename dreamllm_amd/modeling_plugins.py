@@ -212,8 +212,7 @@ class CLIPVisionEmbedding(MultimodalEmbedding):
                                          out_hidden_size=embed_hidden_size, bias=True)
         self.projector.apply(self._init_weights)
         if use_additional_post_layernorm:
-            from .layers import HipLayerNorm
-            self.post_layernorm = HipLayerNorm(embed_hidden_size, eps=self.clip_vision_model.config.layer_norm_eps)
+            self.post_layernorm = ops.HipLayerNorm(embed_hidden_size, eps=self.clip_vision_model.config.layer_norm_eps)
         else:
             self.post_layernorm = nn.Identity()
         self.image_embed_len = (self.clip_vision_model.config.image_size // self.clip_vision_model.config.patch_size) ** 2

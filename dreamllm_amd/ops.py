@@ -1296,3 +1296,10 @@ def rope_append_(q, k, v, kcache, vcache, cos, sin, pos, kv_len=None):
     check("dllm_rope_append", _p(q), _p(k), _p(v), _p(kcache), _p(vcache), _p(cos), _p(sin), _p(pos.reshape(-1)), _p(kv_len), B, H, Hkv, D,
           q.stride(0), k.stride(0), kcache.stride(0), kcache.stride(1), kcache.stride(2), _stream())
     return q
+
+
+class HipLayerNorm(torch.nn.LayerNorm):
+    """nn.LayerNorm shell over the HIP operator (keeps torch.nn's parameter names for state_dict compatibility)."""
+
+    def forward(self, x):
+        return layernorm(x, self.weight, self.bias, self.eps)

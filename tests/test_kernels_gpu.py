@@ -199,9 +199,9 @@ def test_gemm_epilogues(epi, gemm_tile):
 
 @pytest.mark.parametrize("variant", ["plain", "bias_act_res", "accumulate_alpha"])
 def test_gemm_full_tile_epilogue_and_persistent_walk(variant, gemm_tile):
-    """5888 x 5888 outputs = 23 x 23 full 256-tiles (529 >= 2 x 256 CUs: the persistent walk of tile mode 264 engages, and the
-    256-tile kernels take the LDS-staged epilogue on every tile), K = 192 = 3 K tiles (odd: the LDS stage parity flips between
-    consecutive output tiles), with the epilogue variants the LLM uses."""
+    """5888 x 5888 outputs = 23 x 23 full 256-tiles (529 > 2 x 256 CUs: several rounds of blocks per CU, and the 256-tile
+    kernels take the LDS-staged epilogue on every tile), K = 192 = 3 K tiles (odd number of LDS stage flips), with the epilogue
+    variants the LLM uses."""
     ops = _ops()
     torch.manual_seed(11)
     M = N = 5888
