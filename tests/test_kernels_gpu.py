@@ -276,6 +276,8 @@ def attn_variant(request):
     (1, 2, 2, 777, 777, 128, True),    # several 256-query blocks, ragged tail
     (2, 2, 1, 513, 513, 64, True),
     (1, 2, 2, 40, 600, 128, True),     # KV cache: few queries at the end of a long key axis
+    (1, 5, 5, 600, 600, 128, False),   # 5 heads: the XCD-aware work-group map pads the grid to 8 heads
+    (3, 3, 1, 520, 520, 64, True),     # GQA group of 3, 9 query heads / 3 key heads
 ])
 def test_attn_fwd(B, H, Hkv, Sq, Sk, D, causal, attn_variant):
     ops = _ops()
@@ -476,6 +478,9 @@ def test_linear_autograd_and_lm_head_ce(V):
     (2, 2, 1, 513, 513, 64, True),     # GQA over 256-key blocks
     (1, 2, 2, 40, 600, 128, True),     # few queries at the end of a long key axis
     (1, 1, 1, 1024, 1024, 64, False),
+    (1, 5, 5, 600, 600, 128, False),   # non-causal d128 through the split dK / dV kernels, head count not a multiple of 8
+    (3, 3, 1, 520, 520, 64, True),     # GQA group of 3 in the fused d64 dK/dV kernel
+    (1, 2, 2, 2048, 2048, 128, True),  # the headline sequence length: 8 row blocks per head
 ])
 def test_attn_bwd(B, H, Hkv, Sq, Sk, D, causal, attn_variant):
     """dQ/dK/dV against fp32 autograd of the oracle attention.  Bound 1.5e-2: P and dS enter the MFMAs as bf16."""
