@@ -276,232 +276,237 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, t = lane & 15;
     const int nqb = (P.Sq + BQ - 1) / BQ;
-    const AttnBlock bm = attn_block_map<CAUSAL>(nqb, P.H, P.B);
+    // causal: one work-group per PAIR of query blocks (nqb-1-r, r), as in attn_fwd8_kernel: uniform work, head-major order
+    const int nitems = CAUSAL ? (nqb + 1) / 2 : nqb;
+    const AttnBlock bm = attn_block_map<false>(nitems, P.H, P.B);
     if (!bm.valid) return;
     const int b = bm.b, h = bm.h;
-    const int qblk = CAUSAL ? (nqb - 1 - bm.r) : bm.r;
-    const int hk = h / (P.H / P.Hkv);
-    const AttnSpan sp = attn_span(P, b);
-    const int sq_len = sp.sq_len, sk_len = sp.sk_len, SqE = sp.SqE;
-    const int q0 = qblk * BQ, wq0 = q0 + wave * (QT * 16);
-    const int coff = sk_len - sq_len;
-    bf16* dqbase = P.dq + (int64_t)b * P.dq_sb + (int64_t)h * P.dq_sh;
-    const int64_t dq_ss = P.dq_ss;
-    if (sp.qst > 0) {
-        if (qblk == 0) zero_head_rows<D, 512>(dqbase, dq_ss, sp.qst, tid);
-        dqbase += (int64_t)sp.qst * dq_ss;
-    }
-    if (q0 >= sq_len) {
-        for (int i = tid; i < BQ * (D / 8); i += 512) {
-            const int r = q0 + i / (D / 8), c = i % (D / 8);
-            if (r < SqE) st_bf16x8(dqbase + (int64_t)r * dq_ss + c * 8, zero_bf16x8());
+    const int npass = (CAUSAL && nqb - 1 - bm.r != bm.r) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int qblk = CAUSAL ? (pass == 0 ? nqb - 1 - bm.r : bm.r) : bm.r;
+        const int hk = h / (P.H / P.Hkv);
+        const AttnSpan sp = attn_span(P, b);
+        const int sq_len = sp.sq_len, sk_len = sp.sk_len, SqE = sp.SqE;
+        const int q0 = qblk * BQ, wq0 = q0 + wave * (QT * 16);
+        const int coff = sk_len - sq_len;
+        bf16* dqbase = P.dq + (int64_t)b * P.dq_sb + (int64_t)h * P.dq_sh;
+        const int64_t dq_ss = P.dq_ss;
+        if (sp.qst > 0) {
+            if (qblk == 0) zero_head_rows<D, 512>(dqbase, dq_ss, sp.qst, tid);
+            dqbase += (int64_t)sp.qst * dq_ss;
         }
-        return;
-    }
+        if (q0 >= sq_len) {
+            for (int i = tid; i < BQ * (D / 8); i += 512) {
+                const int r = q0 + i / (D / 8), c = i % (D / 8);
+                if (r < SqE) st_bf16x8(dqbase + (int64_t)r * dq_ss + c * 8, zero_bf16x8());
+            }
+            continue;
+        }
 
-    bf16x8 qf[QT][DS], dof[QT][DS];
-    float nlse2[QT], ndlt[QT];
-    {
-        const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
-        const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh + (int64_t)sp.qst * P.o_ss;
-        const float* lsep = P.lse + ((int64_t)b * P.H + h) * P.Sq + sp.qst;
-        const float* dlp = P.delta + ((int64_t)b * P.H + h) * P.Sq + sp.qst;
+        bf16x8 qf[QT][DS], dof[QT][DS];
+        float nlse2[QT], ndlt[QT];
+        {
+            const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
+            const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh + (int64_t)sp.qst * P.o_ss;
+            const float* lsep = P.lse + ((int64_t)b * P.H + h) * P.Sq + sp.qst;
+            const float* dlp = P.delta + ((int64_t)b * P.H + h) * P.Sq + sp.qst;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int qrow = wq0 + qt * 16 + t;
+                const bool ok = qrow < sq_len;  // rows past the end: all-zero operands => S = 0, P = 1, dP - delta = 0, dS = 0
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    qf[qt][ds] = ok ? ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8) : zero_bf16x8();
+                    dof[qt][ds] = ok ? ld_bf16x8(dobase + (int64_t)qrow * P.o_ss + ds * 32 + g * 8) : zero_bf16x8();
+                }
+                nlse2[qt] = ok ? -lsep[qrow] * kLog2e : 0.f;
+                ndlt[qt] = ok ? -dlp[qrow] : 0.f;
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    pin_loaded(qf[qt][ds]);
+                    pin_loaded(dof[qt][ds]);
+                }
+                pin_loaded(nlse2[qt]);
+                pin_loaded(ndlt[qt]);
+            }
+        }
+
+        int kv_end = sk_len;
+        if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
+        const int nblk = kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0;
+        const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+        const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+
+        f32x4 dqacc[DT][QT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) dqacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float sl2 = P.scale * kLog2e;
+
+        char* const Kb0 = smem;
+        char* const Vb0 = smem + 2 * TILE;
+        // LDS-DMA of one tile: the swizzle of the unified image goes on the per-lane SOURCE chunk (the DMA writes lane-linear)
+        constexpr int CPR = D / 8, RPG = 64 / CPR, NDMA = (BKV / RPG) / NW;
+        const int drow = lane / CPR, dpos = lane % CPR;
+        int src_chunk[NDMA];
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) src_chunk[i] = dpos ^ uni_f<D>((wave * NDMA + i) * RPG + drow);
+        auto dma_tile = [&](int row0, int buf) {
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const int grp = wave * NDMA + i;
+                const int row = min(row0 + grp * RPG + drow, sk_len - 1);  // rows past the end: finite data, masked below
+                GLDS16_(kbase + (int64_t)row * P.k_ss + src_chunk[i] * 8, Kb0 + buf * TILE + grp * 1024);
+                GLDS16_(vbase + (int64_t)row * P.k_ss + src_chunk[i] * 8, Vb0 + buf * TILE + grp * 1024);
+            }
+        };
+        auto active = [&](int j) { return (wq0 < sq_len) && !(CAUSAL && j * BKV > wq0 + QT * 16 - 1 + coff); };
+
+        // ---- fragment stream
+        constexpr int NS = 2 * DS;        // steps per segment (= DT)
+        constexpr int NSTEP = 6 * NS;
+        constexpr int PRE = 4, RING = PRE + 1;
+        u32x4 ring[RING];
+        u32x2 rlo[RING], rhi[RING];
+        uint32_t raddr0[DS], raddr[DS];   // row fragments: (row t, chunk ds*4 + g) of the unified image, K buffer 0
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) raddr0[ds] = lds_addr32(Kb0 + t * PITCH + (((ds * 4 + g) ^ uni_f<D>(t)) << 4));
+        // column fragments: row rr = g*4 + t/4, 8 bytes at d = dt*16 + 4*(t&3): chunk dt*2 + ((t>>1)&1), byte (t&1)*8
+        const int rr = g * 4 + (t >> 2);
+        const uint32_t caddr0 = lds_addr32(Kb0 + rr * PITCH + (t & 1) * 8 + ((((t >> 1) & 1) ^ (uni_f<D>(rr) & 1)) << 4));
+        const uint32_t cswz = (uint32_t)((uni_f<D>(rr) >> 1) << 5);
+        uint32_t caddr = caddr0;
+        auto is_col = [](int f) { return f >= 4 * (2 * (D / 32)); };
+        auto issue = [&ring, &rlo, &rhi, &raddr, &caddr, cswz](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int seg = f / NS, i = f % NS;
+            if constexpr (seg < 4) {  // K (even i) or V row fragment of key tile seg, d step i / 2: four accumulator chains in rotation
+                constexpr int off = seg * 16 * PITCH + ((i & 1) == 0 ? 0 : 2 * TILE);
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % RING]) : "v"(raddr[i >> 1]), "n"(off));
+            } else {                  // K column fragment of d tile i, keys of half seg - 4
+                constexpr int ks = seg - 4;
+                const uint32_t a = caddr + ((uint32_t)(i << 5) ^ cswz);
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(rlo[f % RING]) : "v"(a), "n"((2 * ks) * 16 * PITCH));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(rhi[f % RING]) : "v"(a), "n"((2 * ks + 1) * 16 * PITCH));
+            }
+        };
+        auto wait_frag = [&ring, &rlo, &rhi](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int last = f + PRE < NSTEP ? f + PRE : NSTEP - 1;
+            constexpr int younger = [](int f0, int l0) { int n = 0; for (int i = f0 + 1; i <= l0; ++i) n += (i < 8 * (D / 32) ? 1 : 2); return n; }(f, last);
+            static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
+            if constexpr (f < 4 * NS)
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[f % RING]) : "n"(younger) : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(rlo[f % RING]), "+v"(rhi[f % RING]) : "n"(younger) : "memory");
+        };
+        (void)is_col;
+
+        if (nblk > 0) dma_tile(0, 0);
+        __syncthreads();
+
+        for (int j = 0; j < nblk; ++j) {
+            const int kv0 = j * BKV;
+            if (j + 1 < nblk) dma_tile(kv0 + BKV, (j + 1) & 1);
+            if (active(j)) {
+                const uint32_t boff = (uint32_t)((j & 1) * TILE);
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) raddr[ds] = raddr0[ds] + boff;
+                caddr = caddr0 + boff;
+                const bool need_mask = (kv0 + BKV > sk_len) || (CAUSAL && (kv0 + BKV - 1 > wq0 + coff));
+                f32x4 s[2][QT], dp[2][QT];   // scores / dP - delta of the key tile being accumulated and of the previous one
+                bf16x8 dsb[QT][2];           // dS^T as B operands: [k = 32 keys of half ks][n = query]
+                // softmax algebra of elements [e0, e0 + n) of key tile kt (element e: qt = e / 4, r = e % 4)
+                auto sm_slice = [&](auto ktc, int e0, int n) {
+                    constexpr int kt = decltype(ktc)::value;
+#pragma unroll
+                    for (int e = e0; e < e0 + n; e += 2) {
+                        const int qt = e >> 2, r = e & 3;
+                        const float p0 = fast_exp2(fmaf(s[kt & 1][qt][r], sl2, nlse2[qt]));
+                        const float p1 = fast_exp2(fmaf(s[kt & 1][qt][r + 1], sl2, nlse2[qt]));
+                        bf16x2 w;
+                        w[0] = (bf16)(p0 * dp[kt & 1][qt][r]);
+                        w[1] = (bf16)(p1 * dp[kt & 1][qt][r + 1]);
+                        uint32_t u = __builtin_bit_cast(uint32_t, w);
+                        asm volatile("" : "+v"(u));
+                        w = __builtin_bit_cast(bf16x2, u);
+                        dsb[qt][kt >> 1][(kt & 1) * 4 + r] = w[0];
+                        dsb[qt][kt >> 1][(kt & 1) * 4 + r + 1] = w[1];
+                    }
+                };
+                auto mask_tile = [&](auto ktc) {  // diagonal / ragged tiles only: dead (key, query) pairs get P = exp2(-inf) = 0
+                    constexpr int kt = decltype(ktc)::value;
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) {
+                        const int qidx = wq0 + qt * 16 + t;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int kidx = kv0 + kt * 16 + g * 4 + r;
+                            const bool dead = kidx >= sk_len || (CAUSAL && kidx > qidx + coff);
+                            s[kt & 1][qt][r] = dead ? -INFINITY : s[kt & 1][qt][r];
+                        }
+                    }
+                };
+                constexpr int NE = QT * 4;  // softmax elements per key tile and lane
+                static_for_<0, PRE>([&](auto fc) { issue(fc); });
+                static_for_<0, NSTEP>([&](auto sc) {
+                    constexpr int st = decltype(sc)::value;
+                    constexpr int seg = st / NS, i = st % NS;
+                    if constexpr (st + PRE < NSTEP) issue(std::integral_constant<int, st + PRE>{});
+                    if constexpr (seg < 4 && i == 0) {
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) {
+                            s[seg & 1][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            dp[seg & 1][qt] = f32x4{ndlt[qt], ndlt[qt], ndlt[qt], ndlt[qt]};
+                        }
+                    }
+                    if constexpr (seg >= 1 && seg <= 4 && i == 0) {
+                        if (need_mask) mask_tile(std::integral_constant<int, seg - 1>{});
+                    }
+                    wait_frag(sc);
+                    if constexpr (seg < 4) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[st % RING]);
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) {
+                            if constexpr ((i & 1) == 0)
+                                s[seg & 1][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[qt][i >> 1], s[seg & 1][qt], 0, 0, 0);
+                            else
+                                dp[seg & 1][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dof[qt][i >> 1], dp[seg & 1][qt], 0, 0, 0);
+                        }
+                    } else {
+                        constexpr int ks = seg - 4;
+                        const bf16x8 a = join2(rlo[st % RING], rhi[st % RING]);
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt)
+                            dqacc[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsb[qt][ks], dqacc[i][qt], 0, 0, 0);
+                    }
+                    // the previous key tile's softmax algebra, under this segment's MFMAs
+                    if constexpr (seg >= 1 && seg <= 4) sm_slice(std::integral_constant<int, seg - 1>{}, i * NE / NS, NE / NS);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            __syncthreads();
+        }
+
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const int qrow = wq0 + qt * 16 + t;
-            const bool ok = qrow < sq_len;  // rows past the end: all-zero operands => S = 0, P = 1, dP - delta = 0, dS = 0
+            if (qrow < SqE) {
+                const bool ok = qrow < sq_len;
 #pragma unroll
-            for (int ds = 0; ds < DS; ++ds) {
-                qf[qt][ds] = ok ? ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8) : zero_bf16x8();
-                dof[qt][ds] = ok ? ld_bf16x8(dobase + (int64_t)qrow * P.o_ss + ds * 32 + g * 8) : zero_bf16x8();
-            }
-            nlse2[qt] = ok ? -lsep[qrow] * kLog2e : 0.f;
-            ndlt[qt] = ok ? -dlp[qrow] : 0.f;
-        }
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x4 o;
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) {
-                pin_loaded(qf[qt][ds]);
-                pin_loaded(dof[qt][ds]);
-            }
-            pin_loaded(nlse2[qt]);
-            pin_loaded(ndlt[qt]);
-        }
-    }
-
-    int kv_end = sk_len;
-    if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
-    const int nblk = kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0;
-    const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
-    const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
-
-    f32x4 dqacc[DT][QT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) dqacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float sl2 = P.scale * kLog2e;
-
-    char* const Kb0 = smem;
-    char* const Vb0 = smem + 2 * TILE;
-    // LDS-DMA of one tile: the swizzle of the unified image goes on the per-lane SOURCE chunk (the DMA writes lane-linear)
-    constexpr int CPR = D / 8, RPG = 64 / CPR, NDMA = (BKV / RPG) / NW;
-    const int drow = lane / CPR, dpos = lane % CPR;
-    int src_chunk[NDMA];
-#pragma unroll
-    for (int i = 0; i < NDMA; ++i) src_chunk[i] = dpos ^ uni_f<D>((wave * NDMA + i) * RPG + drow);
-    auto dma_tile = [&](int row0, int buf) {
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int grp = wave * NDMA + i;
-            const int row = min(row0 + grp * RPG + drow, sk_len - 1);  // rows past the end: finite data, masked below
-            GLDS16_(kbase + (int64_t)row * P.k_ss + src_chunk[i] * 8, Kb0 + buf * TILE + grp * 1024);
-            GLDS16_(vbase + (int64_t)row * P.k_ss + src_chunk[i] * 8, Vb0 + buf * TILE + grp * 1024);
-        }
-    };
-    auto active = [&](int j) { return (wq0 < sq_len) && !(CAUSAL && j * BKV > wq0 + QT * 16 - 1 + coff); };
-
-    // ---- fragment stream
-    constexpr int NS = 2 * DS;        // steps per segment (= DT)
-    constexpr int NSTEP = 6 * NS;
-    constexpr int PRE = 4, RING = PRE + 1;
-    u32x4 ring[RING];
-    u32x2 rlo[RING], rhi[RING];
-    uint32_t raddr0[DS], raddr[DS];   // row fragments: (row t, chunk ds*4 + g) of the unified image, K buffer 0
-#pragma unroll
-    for (int ds = 0; ds < DS; ++ds) raddr0[ds] = lds_addr32(Kb0 + t * PITCH + (((ds * 4 + g) ^ uni_f<D>(t)) << 4));
-    // column fragments: row rr = g*4 + t/4, 8 bytes at d = dt*16 + 4*(t&3): chunk dt*2 + ((t>>1)&1), byte (t&1)*8
-    const int rr = g * 4 + (t >> 2);
-    const uint32_t caddr0 = lds_addr32(Kb0 + rr * PITCH + (t & 1) * 8 + ((((t >> 1) & 1) ^ (uni_f<D>(rr) & 1)) << 4));
-    const uint32_t cswz = (uint32_t)((uni_f<D>(rr) >> 1) << 5);
-    uint32_t caddr = caddr0;
-    auto is_col = [](int f) { return f >= 4 * (2 * (D / 32)); };
-    auto issue = [&ring, &rlo, &rhi, &raddr, &caddr, cswz](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        constexpr int seg = f / NS, i = f % NS;
-        if constexpr (seg < 4) {  // K (even i) or V row fragment of key tile seg, d step i / 2: four accumulator chains in rotation
-            constexpr int off = seg * 16 * PITCH + ((i & 1) == 0 ? 0 : 2 * TILE);
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % RING]) : "v"(raddr[i >> 1]), "n"(off));
-        } else {                  // K column fragment of d tile i, keys of half seg - 4
-            constexpr int ks = seg - 4;
-            const uint32_t a = caddr + ((uint32_t)(i << 5) ^ cswz);
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(rlo[f % RING]) : "v"(a), "n"((2 * ks) * 16 * PITCH));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(rhi[f % RING]) : "v"(a), "n"((2 * ks + 1) * 16 * PITCH));
-        }
-    };
-    auto wait_frag = [&ring, &rlo, &rhi](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        constexpr int last = f + PRE < NSTEP ? f + PRE : NSTEP - 1;
-        constexpr int younger = [](int f0, int l0) { int n = 0; for (int i = f0 + 1; i <= l0; ++i) n += (i < 8 * (D / 32) ? 1 : 2); return n; }(f, last);
-        static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
-        if constexpr (f < 4 * NS)
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[f % RING]) : "n"(younger) : "memory");
-        else
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(rlo[f % RING]), "+v"(rhi[f % RING]) : "n"(younger) : "memory");
-    };
-    (void)is_col;
-
-    if (nblk > 0) dma_tile(0, 0);
-    __syncthreads();
-
-    for (int j = 0; j < nblk; ++j) {
-        const int kv0 = j * BKV;
-        if (j + 1 < nblk) dma_tile(kv0 + BKV, (j + 1) & 1);
-        if (active(j)) {
-            const uint32_t boff = (uint32_t)((j & 1) * TILE);
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) raddr[ds] = raddr0[ds] + boff;
-            caddr = caddr0 + boff;
-            const bool need_mask = (kv0 + BKV > sk_len) || (CAUSAL && (kv0 + BKV - 1 > wq0 + coff));
-            f32x4 s[2][QT], dp[2][QT];   // scores / dP - delta of the key tile being accumulated and of the previous one
-            bf16x8 dsb[QT][2];           // dS^T as B operands: [k = 32 keys of half ks][n = query]
-            // softmax algebra of elements [e0, e0 + n) of key tile kt (element e: qt = e / 4, r = e % 4)
-            auto sm_slice = [&](auto ktc, int e0, int n) {
-                constexpr int kt = decltype(ktc)::value;
-#pragma unroll
-                for (int e = e0; e < e0 + n; e += 2) {
-                    const int qt = e >> 2, r = e & 3;
-                    const float p0 = fast_exp2(fmaf(s[kt & 1][qt][r], sl2, nlse2[qt]));
-                    const float p1 = fast_exp2(fmaf(s[kt & 1][qt][r + 1], sl2, nlse2[qt]));
-                    bf16x2 w;
-                    w[0] = (bf16)(p0 * dp[kt & 1][qt][r]);
-                    w[1] = (bf16)(p1 * dp[kt & 1][qt][r + 1]);
-                    uint32_t u = __builtin_bit_cast(uint32_t, w);
-                    asm volatile("" : "+v"(u));
-                    w = __builtin_bit_cast(bf16x2, u);
-                    dsb[qt][kt >> 1][(kt & 1) * 4 + r] = w[0];
-                    dsb[qt][kt >> 1][(kt & 1) * 4 + r + 1] = w[1];
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16)(ok ? dqacc[dt][qt][r] * P.scale : 0.f);
+                    st_bf16x4(dqbase + (int64_t)qrow * dq_ss + dt * 16 + g * 4, o);
                 }
-            };
-            auto mask_tile = [&](auto ktc) {  // diagonal / ragged tiles only: dead (key, query) pairs get P = exp2(-inf) = 0
-                constexpr int kt = decltype(ktc)::value;
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    const int qidx = wq0 + qt * 16 + t;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kidx = kv0 + kt * 16 + g * 4 + r;
-                        const bool dead = kidx >= sk_len || (CAUSAL && kidx > qidx + coff);
-                        s[kt & 1][qt][r] = dead ? -INFINITY : s[kt & 1][qt][r];
-                    }
-                }
-            };
-            constexpr int NE = QT * 4;  // softmax elements per key tile and lane
-            static_for_<0, PRE>([&](auto fc) { issue(fc); });
-            static_for_<0, NSTEP>([&](auto sc) {
-                constexpr int st = decltype(sc)::value;
-                constexpr int seg = st / NS, i = st % NS;
-                if constexpr (st + PRE < NSTEP) issue(std::integral_constant<int, st + PRE>{});
-                if constexpr (seg < 4 && i == 0) {
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) {
-                        s[seg & 1][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        dp[seg & 1][qt] = f32x4{ndlt[qt], ndlt[qt], ndlt[qt], ndlt[qt]};
-                    }
-                }
-                if constexpr (seg >= 1 && seg <= 4 && i == 0) {
-                    if (need_mask) mask_tile(std::integral_constant<int, seg - 1>{});
-                }
-                wait_frag(sc);
-                if constexpr (seg < 4) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, ring[st % RING]);
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) {
-                        if constexpr ((i & 1) == 0)
-                            s[seg & 1][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[qt][i >> 1], s[seg & 1][qt], 0, 0, 0);
-                        else
-                            dp[seg & 1][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dof[qt][i >> 1], dp[seg & 1][qt], 0, 0, 0);
-                    }
-                } else {
-                    constexpr int ks = seg - 4;
-                    const bf16x8 a = join2(rlo[st % RING], rhi[st % RING]);
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        dqacc[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsb[qt][ks], dqacc[i][qt], 0, 0, 0);
-                }
-                // the previous key tile's softmax algebra, under this segment's MFMAs
-                if constexpr (seg >= 1 && seg <= 4) sm_slice(std::integral_constant<int, seg - 1>{}, i * NE / NS, NE / NS);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        }
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const int qrow = wq0 + qt * 16 + t;
-        if (qrow < SqE) {
-            const bool ok = qrow < sq_len;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16)(ok ? dqacc[dt][qt][r] * P.scale : 0.f);
-                st_bf16x4(dqbase + (int64_t)qrow * dq_ss + dt * 16 + g * 4, o);
             }
         }
-    }
+    }  // pass
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
@@ -796,230 +801,237 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv8_kernel(AttnParams P) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, t = lane & 15;
-    const AttnBlock bm = attn_block_map<CAUSAL>((P.Sk + BKEYS - 1) / BKEYS, P.Hkv, P.B);  // key block 0 sees the most queries: heavy first
+    // causal: one work-group per PAIR of key blocks (r, nkb-1-r) -- key block 0 sees every query, the last one only its own rows
+    const int nkb = (P.Sk + BKEYS - 1) / BKEYS;
+    const int nitems = CAUSAL ? (nkb + 1) / 2 : nkb;
+    const AttnBlock bm = attn_block_map<false>(nitems, P.Hkv, P.B);
     if (!bm.valid) return;
     const int b = bm.b, hk = bm.h;
     const int group = P.H / P.Hkv;
-    const AttnSpan sp = attn_span(P, b);
-    const int sq_len = sp.sq_len, sk_len = sp.sk_len, SkE = sp.SkE;
-    const int k0 = bm.r * BKEYS, wk0 = k0 + wave * (KT * 16);
-    const int coff = sk_len - sq_len;
-    bf16* dkbase = P.dk + (int64_t)b * P.dk_sb + (int64_t)hk * P.dk_sh;
-    bf16* dvbase = P.dv + (int64_t)b * P.dk_sb + (int64_t)hk * P.dk_sh;
-    const int64_t dk_ss = P.dk_ss;
-    if (sp.kst > 0) {
-        if (bm.r == 0) {
-            if constexpr (kDK) zero_head_rows<D, 512>(dkbase, dk_ss, sp.kst, tid);
-            if constexpr (kDV) zero_head_rows<D, 512>(dvbase, dk_ss, sp.kst, tid);
+    const int npass = (CAUSAL && nkb - 1 - bm.r != bm.r) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int kblk = (CAUSAL && pass == 1) ? nkb - 1 - bm.r : bm.r;
+        const AttnSpan sp = attn_span(P, b);
+        const int sq_len = sp.sq_len, sk_len = sp.sk_len, SkE = sp.SkE;
+        const int k0 = kblk * BKEYS, wk0 = k0 + wave * (KT * 16);
+        const int coff = sk_len - sq_len;
+        bf16* dkbase = P.dk + (int64_t)b * P.dk_sb + (int64_t)hk * P.dk_sh;
+        bf16* dvbase = P.dv + (int64_t)b * P.dk_sb + (int64_t)hk * P.dk_sh;
+        const int64_t dk_ss = P.dk_ss;
+        if (sp.kst > 0) {
+            if (kblk == 0) {
+                if constexpr (kDK) zero_head_rows<D, 512>(dkbase, dk_ss, sp.kst, tid);
+                if constexpr (kDV) zero_head_rows<D, 512>(dvbase, dk_ss, sp.kst, tid);
+            }
+            dkbase += (int64_t)sp.kst * dk_ss;
+            dvbase += (int64_t)sp.kst * dk_ss;
         }
-        dkbase += (int64_t)sp.kst * dk_ss;
-        dvbase += (int64_t)sp.kst * dk_ss;
-    }
 
-    bf16x8 kfB[KT][DS], vfB[KT][DS];
-    {
-        const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
-        const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+        bf16x8 kfB[KT][DS], vfB[KT][DS];
+        {
+            const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+            const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int krow = wk0 + kt * 16 + t;
+                const bool ok = krow < sk_len;
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    kfB[kt][ds] = ok ? ld_bf16x8(kbase + (int64_t)krow * P.k_ss + ds * 32 + g * 8) : zero_bf16x8();
+                    if constexpr (kDK) vfB[kt][ds] = ok ? ld_bf16x8(vbase + (int64_t)krow * P.k_ss + ds * 32 + g * 8) : zero_bf16x8();
+                }
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    pin_loaded(kfB[kt][ds]);
+                    if constexpr (kDK) pin_loaded(vfB[kt][ds]);
+                }
+        }
+        f32x4 dkacc[DT][KT], dvacc[DT][KT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                dkacc[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dvacc[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        const float sl2 = P.scale * kLog2e;
+
+        int qb_begin = 0;
+        if (CAUSAL) qb_begin = max(0, k0 - coff) / BQ;
+        const int qb_end = (sq_len + BQ - 1) / BQ;
+        const int nq = (k0 < sk_len && qb_end > qb_begin) ? (qb_end - qb_begin) : 0;
+        const int niter = nq * group;
+
+        // LDS-DMA of one Q / dO tile pair + statistics (swizzle on the per-lane source chunk; rows past the end are clamped: finite
+        // data, masked below)
+        constexpr int CPR = D / 8, RPG = 64 / CPR, NDMA = (BQ / RPG) / NW;
+        const int drow = lane / CPR, dpos = lane % CPR;
+        int src_chunk[NDMA];
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) src_chunk[i] = dpos ^ uni_f<D>((wave * NDMA + i) * RPG + drow);
+        const int64_t plane = (int64_t)P.B * P.H * P.Sq;
+        auto dma_tile = [&](int it, int buf) {
+            const int hq = hk * group + it / nq;
+            const int row0 = (qb_begin + it % nq) * BQ;
+            const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)hq * P.q_sh + (int64_t)sp.qst * P.q_ss;
+            const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)hq * P.o_sh + (int64_t)sp.qst * P.o_ss;
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const int grp = wave * NDMA + i;
+                const int row = min(row0 + grp * RPG + drow, sq_len - 1);
+                GLDS16_(qbase + (int64_t)row * P.q_ss + src_chunk[i] * 8, smem + buf * BUF + grp * 1024);
+                GLDS16_(dobase + (int64_t)row * P.o_ss + src_chunk[i] * 8, smem + buf * BUF + TILE + grp * 1024);
+            }
+            if (wave < (kDK ? 2 : 1)) {  // planes 2 (-lse/scale) and 1 (-delta) of the statistics workspace
+                const float* src = P.delta + (wave == 0 ? 2 : 1) * plane + ((int64_t)b * P.H + hq) * P.Sq + sp.qst;
+                GLDS4_(src + min(row0 + lane, sq_len - 1), smem + STAT0 + buf * 512 + wave * 256);
+            }
+        };
+
+        // ---- fragment stream of one tile (DkvStream).  ring slot = f % RING with RING = PRE + 2: a slot is overwritten two steps
+        // after its own step, so a seed vector is still there when the next step's MFMA takes it as src C.
+        constexpr int NF = St::NF;
+        constexpr int PRE = 3, RING = PRE + 2;
+        u32x4 ring[RING];
+        // row fragments: tile row t, chunk (ds*4 + g) ^ uni_f(t): base + ((ds << 6) ^ rswz); column fragments as in the dQ kernel
+        uint32_t rbase = lds_addr32(smem + t * PITCH + ((g ^ (uni_f<D>(t) & 3)) << 4));
+        const uint32_t rswz = (uint32_t)((uni_f<D>(t) >> 2) << 6);
+        const int rr = g * 4 + (t >> 2);
+        uint32_t cbase = lds_addr32(smem + rr * PITCH + (t & 1) * 8 + ((((t >> 1) & 1) ^ (uni_f<D>(rr) & 1)) << 4));
+        const uint32_t cswz = (uint32_t)((uni_f<D>(rr) >> 1) << 5);
+        uint32_t sbase = lds_addr32(smem + STAT0 + g * 16);
+        auto issue = [&ring, &rbase, &cbase, &sbase, rswz, cswz](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr DkvFrag fr = St::at(f);
+            constexpr int qi = 2 * fr.c + fr.u;
+            if constexpr (fr.kind < 2) {  // 4 consecutive rows g*4.. of the 16-row tile
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % RING]) : "v"(sbase), "n"(qi * 64 + fr.kind * 256));
+            } else if constexpr (fr.kind < 4) {
+                const uint32_t a = rbase + ((uint32_t)(fr.x << 6) ^ rswz);
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % RING]) : "v"(a), "n"((fr.kind - 2) * TILE + qi * 16 * PITCH));
+            } else {
+                const uint32_t a = cbase + ((uint32_t)(fr.x << 5) ^ cswz);
+                u32x2 lo, hi;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"((5 - fr.kind) * TILE + (2 * fr.c) * 16 * PITCH));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"((5 - fr.kind) * TILE + (2 * fr.c + 1) * 16 * PITCH));
+                ring[f % RING] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+            }
+        };
+        auto wait_frag = [&ring](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            constexpr int last = f + PRE < NF ? f + PRE : NF - 1;
+            constexpr int younger = [](int f0, int l0) { int n = 0; for (int i = f0 + 1; i <= l0; ++i) n += St::ops(i); return n; }(f, last);
+            static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[f % RING]) : "n"(younger) : "memory");
+        };
+
+        if (niter > 0) dma_tile(0, 0);
+        __syncthreads();
+
+        for (int it = 0; it < niter; ++it) {
+            if (it + 1 < niter) dma_tile(it + 1, (it + 1) & 1);
+            const int qb0 = (qb_begin + it % nq) * BQ;
+            const bool wave_active = (wk0 < sk_len) && !(CAUSAL && wk0 > qb0 + BQ - 1 + coff);
+            if (wave_active) {
+                const bool need_mask = (qb0 + BQ > sq_len) || (wk0 + KT * 16 > sk_len) || (CAUSAL && (wk0 + KT * 16 - 1 > qb0 + coff));
+                f32x4 sc[KT], dp[KT];
+                bf16x8 pb[KT], dsb[KT];
+                static_for_<0, PRE>([&](auto fc) { issue(fc); });
+                static_for_<0, NF>([&](auto fc) {
+                    constexpr int f = decltype(fc)::value;
+                    constexpr DkvFrag fr = St::at(f);
+                    if constexpr (f + PRE < NF) issue(std::integral_constant<int, f + PRE>{});
+                    wait_frag(fc);
+                    if constexpr (fr.kind == 2 || fr.kind == 3) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[f % RING]);
+                        if constexpr (fr.first) {  // first MFMA of the chain: src C = the statistic vector read one step earlier
+                            const f32x4 seed = __builtin_bit_cast(f32x4, ring[(f - 1) % RING]);
+#pragma unroll
+                            for (int kt = 0; kt < KT; ++kt) {
+                                if constexpr (fr.kind == 2)
+                                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kfB[kt][fr.x], seed, 0, 0, 0);
+                                else
+                                    dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, vfB[kt][fr.x], seed, 0, 0, 0);
+                            }
+                        } else {
+#pragma unroll
+                            for (int kt = 0; kt < KT; ++kt) {
+                                if constexpr (fr.kind == 2)
+                                    sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kfB[kt][fr.x], sc[kt], 0, 0, 0);
+                                else
+                                    dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, vfB[kt][fr.x], dp[kt], 0, 0, 0);
+                            }
+                        }
+                    } else if constexpr (fr.kind >= 4) {
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[f % RING]);
+#pragma unroll
+                        for (int kt = 0; kt < KT; ++kt) {
+                            if constexpr (fr.kind == 4)
+                                dvacc[fr.x][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[kt], dvacc[fr.x][kt], 0, 0, 0);
+                            else
+                                dkacc[fr.x][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsb[kt], dkacc[fr.x][kt], 0, 0, 0);
+                        }
+                    }
+                    if constexpr (St::last_of_p1(f)) {  // S' (and dP') of 16 rows x 32 keys complete: P, dS -> B operands of phase 2
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (need_mask) {
+#pragma unroll
+                            for (int kt = 0; kt < KT; ++kt) {
+                                const int kidx = wk0 + kt * 16 + t;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int qidx = qb0 + (2 * fr.c + fr.u) * 16 + g * 4 + r;
+                                    const bool dead = qidx >= sq_len || kidx >= sk_len || (CAUSAL && kidx > qidx + coff);
+                                    sc[kt][r] = dead ? -INFINITY : sc[kt][r];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                            for (int r = 0; r < 4; r += 2) {
+                                const float p0 = fast_exp2(sc[kt][r] * sl2), p1 = fast_exp2(sc[kt][r + 1] * sl2);
+                                if constexpr (kDV) {
+                                    pb[kt][fr.u * 4 + r] = (bf16)p0;
+                                    pb[kt][fr.u * 4 + r + 1] = (bf16)p1;
+                                }
+                                if constexpr (kDK) {
+                                    dsb[kt][fr.u * 4 + r] = (bf16)(p0 * dp[kt][r]);
+                                    dsb[kt][fr.u * 4 + r + 1] = (bf16)(p1 * dp[kt][r + 1]);
+                                }
+                            }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            }
+            rbase ^= BUF;  // the other tile buffer (the dynamic LDS segment starts at address 0)
+            cbase ^= BUF;
+            sbase ^= 512;
+            __syncthreads();
+        }
+
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
             const int krow = wk0 + kt * 16 + t;
-            const bool ok = krow < sk_len;
+            if (krow < SkE) {
+                const bool ok = krow < sk_len;
 #pragma unroll
-            for (int ds = 0; ds < DS; ++ds) {
-                kfB[kt][ds] = ok ? ld_bf16x8(kbase + (int64_t)krow * P.k_ss + ds * 32 + g * 8) : zero_bf16x8();
-                if constexpr (kDK) vfB[kt][ds] = ok ? ld_bf16x8(vbase + (int64_t)krow * P.k_ss + ds * 32 + g * 8) : zero_bf16x8();
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x4 ok_, ov_;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ok_[r] = (bf16)(ok ? dkacc[dt][kt][r] * P.scale : 0.f);
+                        ov_[r] = (bf16)(ok ? dvacc[dt][kt][r] : 0.f);
+                    }
+                    if constexpr (kDK) st_bf16x4(dkbase + (int64_t)krow * dk_ss + dt * 16 + g * 4, ok_);
+                    if constexpr (kDV) st_bf16x4(dvbase + (int64_t)krow * dk_ss + dt * 16 + g * 4, ov_);
+                }
             }
         }
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) {
-                pin_loaded(kfB[kt][ds]);
-                if constexpr (kDK) pin_loaded(vfB[kt][ds]);
-            }
-    }
-    f32x4 dkacc[DT][KT], dvacc[DT][KT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            dkacc[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dvacc[dt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    const float sl2 = P.scale * kLog2e;
-
-    int qb_begin = 0;
-    if (CAUSAL) qb_begin = max(0, k0 - coff) / BQ;
-    const int qb_end = (sq_len + BQ - 1) / BQ;
-    const int nq = (k0 < sk_len && qb_end > qb_begin) ? (qb_end - qb_begin) : 0;
-    const int niter = nq * group;
-
-    // LDS-DMA of one Q / dO tile pair + statistics (swizzle on the per-lane source chunk; rows past the end are clamped: finite
-    // data, masked below)
-    constexpr int CPR = D / 8, RPG = 64 / CPR, NDMA = (BQ / RPG) / NW;
-    const int drow = lane / CPR, dpos = lane % CPR;
-    int src_chunk[NDMA];
-#pragma unroll
-    for (int i = 0; i < NDMA; ++i) src_chunk[i] = dpos ^ uni_f<D>((wave * NDMA + i) * RPG + drow);
-    const int64_t plane = (int64_t)P.B * P.H * P.Sq;
-    auto dma_tile = [&](int it, int buf) {
-        const int hq = hk * group + it / nq;
-        const int row0 = (qb_begin + it % nq) * BQ;
-        const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)hq * P.q_sh + (int64_t)sp.qst * P.q_ss;
-        const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)hq * P.o_sh + (int64_t)sp.qst * P.o_ss;
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int grp = wave * NDMA + i;
-            const int row = min(row0 + grp * RPG + drow, sq_len - 1);
-            GLDS16_(qbase + (int64_t)row * P.q_ss + src_chunk[i] * 8, smem + buf * BUF + grp * 1024);
-            GLDS16_(dobase + (int64_t)row * P.o_ss + src_chunk[i] * 8, smem + buf * BUF + TILE + grp * 1024);
-        }
-        if (wave < (kDK ? 2 : 1)) {  // planes 2 (-lse/scale) and 1 (-delta) of the statistics workspace
-            const float* src = P.delta + (wave == 0 ? 2 : 1) * plane + ((int64_t)b * P.H + hq) * P.Sq + sp.qst;
-            GLDS4_(src + min(row0 + lane, sq_len - 1), smem + STAT0 + buf * 512 + wave * 256);
-        }
-    };
-
-    // ---- fragment stream of one tile (DkvStream).  ring slot = f % RING with RING = PRE + 2: a slot is overwritten two steps
-    // after its own step, so a seed vector is still there when the next step's MFMA takes it as src C.
-    constexpr int NF = St::NF;
-    constexpr int PRE = 3, RING = PRE + 2;
-    u32x4 ring[RING];
-    // row fragments: tile row t, chunk (ds*4 + g) ^ uni_f(t): base + ((ds << 6) ^ rswz); column fragments as in the dQ kernel
-    uint32_t rbase = lds_addr32(smem + t * PITCH + ((g ^ (uni_f<D>(t) & 3)) << 4));
-    const uint32_t rswz = (uint32_t)((uni_f<D>(t) >> 2) << 6);
-    const int rr = g * 4 + (t >> 2);
-    uint32_t cbase = lds_addr32(smem + rr * PITCH + (t & 1) * 8 + ((((t >> 1) & 1) ^ (uni_f<D>(rr) & 1)) << 4));
-    const uint32_t cswz = (uint32_t)((uni_f<D>(rr) >> 1) << 5);
-    uint32_t sbase = lds_addr32(smem + STAT0 + g * 16);
-    auto issue = [&ring, &rbase, &cbase, &sbase, rswz, cswz](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        constexpr DkvFrag fr = St::at(f);
-        constexpr int qi = 2 * fr.c + fr.u;
-        if constexpr (fr.kind < 2) {  // 4 consecutive rows g*4.. of the 16-row tile
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % RING]) : "v"(sbase), "n"(qi * 64 + fr.kind * 256));
-        } else if constexpr (fr.kind < 4) {
-            const uint32_t a = rbase + ((uint32_t)(fr.x << 6) ^ rswz);
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[f % RING]) : "v"(a), "n"((fr.kind - 2) * TILE + qi * 16 * PITCH));
-        } else {
-            const uint32_t a = cbase + ((uint32_t)(fr.x << 5) ^ cswz);
-            u32x2 lo, hi;
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"((5 - fr.kind) * TILE + (2 * fr.c) * 16 * PITCH));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"((5 - fr.kind) * TILE + (2 * fr.c + 1) * 16 * PITCH));
-            ring[f % RING] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        }
-    };
-    auto wait_frag = [&ring](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        constexpr int last = f + PRE < NF ? f + PRE : NF - 1;
-        constexpr int younger = [](int f0, int l0) { int n = 0; for (int i = f0 + 1; i <= l0; ++i) n += St::ops(i); return n; }(f, last);
-        static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
-        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[f % RING]) : "n"(younger) : "memory");
-    };
-
-    if (niter > 0) dma_tile(0, 0);
-    __syncthreads();
-
-    for (int it = 0; it < niter; ++it) {
-        if (it + 1 < niter) dma_tile(it + 1, (it + 1) & 1);
-        const int qb0 = (qb_begin + it % nq) * BQ;
-        const bool wave_active = (wk0 < sk_len) && !(CAUSAL && wk0 > qb0 + BQ - 1 + coff);
-        if (wave_active) {
-            const bool need_mask = (qb0 + BQ > sq_len) || (wk0 + KT * 16 > sk_len) || (CAUSAL && (wk0 + KT * 16 - 1 > qb0 + coff));
-            f32x4 sc[KT], dp[KT];
-            bf16x8 pb[KT], dsb[KT];
-            static_for_<0, PRE>([&](auto fc) { issue(fc); });
-            static_for_<0, NF>([&](auto fc) {
-                constexpr int f = decltype(fc)::value;
-                constexpr DkvFrag fr = St::at(f);
-                if constexpr (f + PRE < NF) issue(std::integral_constant<int, f + PRE>{});
-                wait_frag(fc);
-                if constexpr (fr.kind == 2 || fr.kind == 3) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, ring[f % RING]);
-                    if constexpr (fr.first) {  // first MFMA of the chain: src C = the statistic vector read one step earlier
-                        const f32x4 seed = __builtin_bit_cast(f32x4, ring[(f - 1) % RING]);
-#pragma unroll
-                        for (int kt = 0; kt < KT; ++kt) {
-                            if constexpr (fr.kind == 2)
-                                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kfB[kt][fr.x], seed, 0, 0, 0);
-                            else
-                                dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, vfB[kt][fr.x], seed, 0, 0, 0);
-                        }
-                    } else {
-#pragma unroll
-                        for (int kt = 0; kt < KT; ++kt) {
-                            if constexpr (fr.kind == 2)
-                                sc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, kfB[kt][fr.x], sc[kt], 0, 0, 0);
-                            else
-                                dp[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, vfB[kt][fr.x], dp[kt], 0, 0, 0);
-                        }
-                    }
-                } else if constexpr (fr.kind >= 4) {
-                    const bf16x8 a = __builtin_bit_cast(bf16x8, ring[f % RING]);
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt) {
-                        if constexpr (fr.kind == 4)
-                            dvacc[fr.x][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb[kt], dvacc[fr.x][kt], 0, 0, 0);
-                        else
-                            dkacc[fr.x][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsb[kt], dkacc[fr.x][kt], 0, 0, 0);
-                    }
-                }
-                if constexpr (St::last_of_p1(f)) {  // S' (and dP') of 16 rows x 32 keys complete: P, dS -> B operands of phase 2
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (need_mask) {
-#pragma unroll
-                        for (int kt = 0; kt < KT; ++kt) {
-                            const int kidx = wk0 + kt * 16 + t;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const int qidx = qb0 + (2 * fr.c + fr.u) * 16 + g * 4 + r;
-                                const bool dead = qidx >= sq_len || kidx >= sk_len || (CAUSAL && kidx > qidx + coff);
-                                sc[kt][r] = dead ? -INFINITY : sc[kt][r];
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                        for (int r = 0; r < 4; r += 2) {
-                            const float p0 = fast_exp2(sc[kt][r] * sl2), p1 = fast_exp2(sc[kt][r + 1] * sl2);
-                            if constexpr (kDV) {
-                                pb[kt][fr.u * 4 + r] = (bf16)p0;
-                                pb[kt][fr.u * 4 + r + 1] = (bf16)p1;
-                            }
-                            if constexpr (kDK) {
-                                dsb[kt][fr.u * 4 + r] = (bf16)(p0 * dp[kt][r]);
-                                dsb[kt][fr.u * 4 + r + 1] = (bf16)(p1 * dp[kt][r + 1]);
-                            }
-                        }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        }
-        rbase ^= BUF;  // the other tile buffer (the dynamic LDS segment starts at address 0)
-        cbase ^= BUF;
-        sbase ^= 512;
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-        const int krow = wk0 + kt * 16 + t;
-        if (krow < SkE) {
-            const bool ok = krow < sk_len;
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                bf16x4 ok_, ov_;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ok_[r] = (bf16)(ok ? dkacc[dt][kt][r] * P.scale : 0.f);
-                    ov_[r] = (bf16)(ok ? dvacc[dt][kt][r] : 0.f);
-                }
-                if constexpr (kDK) st_bf16x4(dkbase + (int64_t)krow * dk_ss + dt * 16 + g * 4, ok_);
-                if constexpr (kDV) st_bf16x4(dvbase + (int64_t)krow * dk_ss + dt * 16 + g * 4, ov_);
-            }
-        }
-    }
+    }  // pass
 }
 
 template <int D, bool CAUSAL>
@@ -1035,7 +1047,8 @@ int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_
     constexpr int BQ = 4 * QT * 16, BKEYS = 4 * KT * 16;
     if (wide_dq) {
         dllm_ensure_dyn_lds(&attn_bwd_dq8_kernel<D, CAUSAL>, LDS_DQ, lds3_ok);
-        hipLaunchKernelGGL((attn_bwd_dq8_kernel<D, CAUSAL>), dim3(attn_grid((P.Sq + 255) / 256, P.H, P.B)), dim3(512), LDS_DQ, stream, P);
+        const int nqb8 = (P.Sq + 255) / 256;  // causal: one group per pair of row blocks
+        hipLaunchKernelGGL((attn_bwd_dq8_kernel<D, CAUSAL>), dim3(attn_grid(CAUSAL ? (nqb8 + 1) / 2 : nqb8, P.H, P.B)), dim3(512), LDS_DQ, stream, P);
     } else {
         dllm_ensure_dyn_lds(&attn_bwd_dq_kernel<D, CAUSAL, QT>, LDS_DQ, lds_ok);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL, QT>), dim3(attn_grid((P.Sq + BQ - 1) / BQ, P.H, P.B)), dim3(256), LDS_DQ, stream, P);
@@ -1043,7 +1056,8 @@ int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_
     if (wide_dkv) {
         constexpr int LDS_DKV8 = 2 * (2 * 64 * D * 2) + 1024;
         static_assert(((2 * 64 * D * 2) & (2 * 64 * D * 2 - 1)) == 0, "buffer toggling by XOR");
-        const dim3 grid8(attn_grid((P.Sk + 255) / 256, P.Hkv, P.B));
+        const int nkb8 = (P.Sk + 255) / 256;
+        const dim3 grid8(attn_grid(CAUSAL ? (nkb8 + 1) / 2 : nkb8, P.Hkv, P.B));
         if constexpr (D == 128) {
             dllm_ensure_dyn_lds(&attn_bwd_dkv8_kernel<D, CAUSAL, 1>, LDS_DKV8, lds4_ok);
             dllm_ensure_dyn_lds(&attn_bwd_dkv8_kernel<D, CAUSAL, 2>, LDS_DKV8, lds5_ok);

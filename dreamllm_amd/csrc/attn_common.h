@@ -178,25 +178,17 @@ struct AttnBlock {
     int r, h, b;   // row block (in dispatch order: 0 = first), head, batch
     bool valid;
 };
-// LPT = true (causal 8-wave kernels): an XCD takes the row blocks of ALL its heads heaviest first -- the dispatcher's greedy
-// placement of a sorted list ends with the short blocks, so the tail of the kernel is one light block instead of one heavy one
-// (+8 % on the 256-row causal kernels).  The price is that the blocks of one head no longer run together (its K / V come from
-// MALL / HBM for every block instead of the XCD's L2), which costs the 4-wave kernels (twice the blocks per head) more than the
-// balance gives: they, and the uniform non-causal grids, keep the head-major order.
-template <bool LPT>
+// Causal 8-wave kernels do not hand out single row blocks at all: a work-group takes the PAIR (heaviest remaining, lightest
+// remaining) = (nrb-1-r, r), so every group does the same number of key tiles.  (An LPT order -- an XCD walks the row blocks of
+// ALL its heads heaviest first -- balanced the tail as well, +8 %, but gave up the L2 sharing between a head's blocks; pairing
+// gives both, another +5...10 %.)
+template <bool UNUSED = false>
 __device__ __forceinline__ AttnBlock attn_block_map(int nrow_blocks, int heads, int B) {
     const int L = blockIdx.x;
     const int xcd = L & 7, s = L >> 3;
     AttnBlock m;
-    int slot;
-    if constexpr (LPT) {
-        const int hpx = (heads * B + 7) / 8;
-        slot = s % hpx;
-        m.r = s / hpx;
-    } else {
-        slot = s / nrow_blocks;
-        m.r = s - slot * nrow_blocks;
-    }
+    const int slot = s / nrow_blocks;
+    m.r = s - slot * nrow_blocks;
     const int bh = slot * 8 + xcd;
     m.h = bh % heads;
     m.b = bh / heads;

@@ -298,295 +298,302 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
     const int g = lane >> 4, t = lane & 15;
     constexpr int BQ_ = (8 * 2) * 16;
     const int nqb = (P.Sq + BQ_ - 1) / BQ_;
-    const AttnBlock bm = attn_block_map<CAUSAL>(nqb, P.H, P.B);
+    // Causal: one work-group takes the PAIR of query blocks (nqb-1-r, r) -- heaviest with lightest -- so every group does the same
+    // (nqb + 1) key tiles: the grid is uniform (no tail of stragglers), launch / prologue / epilogue cost is paid per pair, and the
+    // head-major order keeps a head's groups together on one XCD's L2.
+    const int nitems = CAUSAL ? (nqb + 1) / 2 : nqb;
+    const AttnBlock bm = attn_block_map<false>(nitems, P.H, P.B);
     if (!bm.valid) return;
     const int b = bm.b, h = bm.h;
-    const int qblk = CAUSAL ? (nqb - 1 - bm.r) : bm.r;  // heavy causal blocks first
-    const int hk = h / (P.H / P.Hkv);
-    const AttnSpan sp = attn_span(P, b);
-    const int sq_len = sp.sq_len, sk_len = sp.sk_len, SqE = sp.SqE;
-    const int q0 = qblk * BQ, wq0 = q0 + wave * (QT * 16);
-    const int coff = sk_len - sq_len;
+    const int npass = (CAUSAL && nqb - 1 - bm.r != bm.r) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int qblk = CAUSAL ? (pass == 0 ? nqb - 1 - bm.r : bm.r) : bm.r;
+        const int hk = h / (P.H / P.Hkv);
+        const AttnSpan sp = attn_span(P, b);
+        const int sq_len = sp.sq_len, sk_len = sp.sk_len, SqE = sp.SqE;
+        const int q0 = qblk * BQ, wq0 = q0 + wave * (QT * 16);
+        const int coff = sk_len - sq_len;
 
-    bf16* obase = P.o + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh;
-    float* lsebase = P.lse ? P.lse + ((int64_t)b * P.H + h) * P.Sq : nullptr;
-    if (sp.qst > 0) {
-        if (qblk == 0) {
-            zero_head_rows<D, 512>(obase, P.o_ss, sp.qst, tid);
+        bf16* obase = P.o + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh;
+        float* lsebase = P.lse ? P.lse + ((int64_t)b * P.H + h) * P.Sq : nullptr;
+        if (sp.qst > 0) {
+            if (qblk == 0) {
+                zero_head_rows<D, 512>(obase, P.o_ss, sp.qst, tid);
+                if (lsebase)
+                    for (int i = tid; i < sp.qst; i += 512) lsebase[i] = 0.f;
+            }
+            obase += (int64_t)sp.qst * P.o_ss;
+            if (lsebase) lsebase += sp.qst;
+        }
+        if (q0 >= sq_len) {  // padded tail: zeros (pad_input semantics, modeling_dreamllm.py:545)
+            for (int i = tid; i < BQ * (D / 8); i += 512) {
+                const int r = q0 + i / (D / 8), c = i % (D / 8);
+                if (r < SqE) st_bf16x8(obase + (int64_t)r * P.o_ss + c * 8, zero_bf16x8());
+            }
             if (lsebase)
-                for (int i = tid; i < sp.qst; i += 512) lsebase[i] = 0.f;
+                for (int i = tid; i < BQ; i += 512)
+                    if (q0 + i < SqE) lsebase[q0 + i] = 0.f;
+            continue;
         }
-        obase += (int64_t)sp.qst * P.o_ss;
-        if (lsebase) lsebase += sp.qst;
-    }
-    if (q0 >= sq_len) {  // padded tail: zeros (pad_input semantics, modeling_dreamllm.py:545)
-        for (int i = tid; i < BQ * (D / 8); i += 512) {
-            const int r = q0 + i / (D / 8), c = i % (D / 8);
-            if (r < SqE) st_bf16x8(obase + (int64_t)r * P.o_ss + c * 8, zero_bf16x8());
-        }
-        if (lsebase)
-            for (int i = tid; i < BQ; i += 512)
-                if (q0 + i < SqE) lsebase[q0 + i] = 0.f;
-        return;
-    }
 
-    bf16x8 qf[QT][DS];
-    {
-        const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
+        bf16x8 qf[QT][DS];
+        {
+            const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int qrow = min(wq0 + qt * 16 + t, sq_len - 1);
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) qf[qt][ds] = ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8);
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) pin_loaded(qf[qt][ds]);
+        }
+
+        int kv_end = sk_len;
+        if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
+        const int nblk = kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0;
+        const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+        const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+
+        f32x4 oacc[DT][QT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) oacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 lacc[QT];  // row sums on the matrix pipe: every row of this accumulator holds sum_k P[k][q]
+        float m_run[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            const int qrow = min(wq0 + qt * 16 + t, sq_len - 1);
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) qf[qt][ds] = ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8);
+            lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            m_run[qt] = kNegBig;  // finite "minus infinity": no special cases in the bookkeeping (exp2 of -huge is exactly 0)
         }
+        const float sl2 = P.scale * kLog2e;
+        bf16x8 ones;
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) pin_loaded(qf[qt][ds]);
-    }
+        for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
-    int kv_end = sk_len;
-    if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
-    const int nblk = kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0;
-    const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
-    const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
-
-    f32x4 oacc[DT][QT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) oacc[dt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 lacc[QT];  // row sums on the matrix pipe: every row of this accumulator holds sum_k P[k][q]
-    float m_run[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        lacc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        m_run[qt] = kNegBig;  // finite "minus infinity": no special cases in the bookkeeping (exp2 of -huge is exactly 0)
-    }
-    const float sl2 = P.scale * kLog2e;
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
-
-    char* const Kb0 = smem;
-    char* const Vb0 = smem + 2 * TILE;
-    // K / V tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass, no address VALU per
-    // store).  The DMA writes wave-uniform base + lane * 16, so the XOR swizzles of the two LDS images are applied to the
-    // per-lane SOURCE chunk (a permutation inside one row: coalescing is unaffected).  A wave moves NDMA 1-KiB groups of RPG
-    // rows per tile; every LDS read of this kernel is inline asm (below), so hipcc has no visible LDS read in front of which it
-    // would drain the DMA queue.
-    constexpr int CPR = D / 8;             // 16-byte chunks per row
-    constexpr int RPG = 64 / CPR;          // rows per 1-KiB group (4 at D = 128, 8 at D = 64)
-    constexpr int NDMA = (BKV / RPG) / NW; // groups per wave per tile (2 / 1)
-    const int drow = lane / CPR, dpos = lane % CPR;
-    int k_src_chunk[NDMA], v_src_chunk[NDMA];
-#pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-        const int r = (wave * NDMA + i) * RPG + drow;
-        if constexpr (D == 128) {
-            k_src_chunk[i] = dpos ^ (r & 15);
-            v_src_chunk[i] = (((dpos >> 1) ^ (r & 7)) << 1) | (dpos & 1);
-        } else {
-            k_src_chunk[i] = dpos ^ ((r >> 1) & 7);
-            v_src_chunk[i] = (((dpos >> 1) ^ ((r >> 1) & 3)) << 1) | (dpos & 1);
-        }
-    }
-    auto dma_tile = [&](int row0, int buf) {
+        char* const Kb0 = smem;
+        char* const Vb0 = smem + 2 * TILE;
+        // K / V tiles arrive by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass, no address VALU per
+        // store).  The DMA writes wave-uniform base + lane * 16, so the XOR swizzles of the two LDS images are applied to the
+        // per-lane SOURCE chunk (a permutation inside one row: coalescing is unaffected).  A wave moves NDMA 1-KiB groups of RPG
+        // rows per tile; every LDS read of this kernel is inline asm (below), so hipcc has no visible LDS read in front of which it
+        // would drain the DMA queue.
+        constexpr int CPR = D / 8;             // 16-byte chunks per row
+        constexpr int RPG = 64 / CPR;          // rows per 1-KiB group (4 at D = 128, 8 at D = 64)
+        constexpr int NDMA = (BKV / RPG) / NW; // groups per wave per tile (2 / 1)
+        const int drow = lane / CPR, dpos = lane % CPR;
+        int k_src_chunk[NDMA], v_src_chunk[NDMA];
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
-            const int grp = wave * NDMA + i;
-            const int row = min(row0 + grp * RPG + drow, sk_len - 1);  // rows past the end: any finite data (masked later)
-            GLDS16_(kbase + (int64_t)row * P.k_ss + k_src_chunk[i] * 8, Kb0 + buf * TILE + grp * 1024);
-            GLDS16_(vbase + (int64_t)row * P.k_ss + v_src_chunk[i] * 8, Vb0 + buf * TILE + grp * 1024);
+            const int r = (wave * NDMA + i) * RPG + drow;
+            if constexpr (D == 128) {
+                k_src_chunk[i] = dpos ^ (r & 15);
+                v_src_chunk[i] = (((dpos >> 1) ^ (r & 7)) << 1) | (dpos & 1);
+            } else {
+                k_src_chunk[i] = dpos ^ ((r >> 1) & 7);
+                v_src_chunk[i] = (((dpos >> 1) ^ ((r >> 1) & 3)) << 1) | (dpos & 1);
+            }
         }
-    };
-    // a wave takes part in tile j iff one of its queries can see one of the tile's keys
-    auto active = [&](int j) { return (wq0 < sq_len) && !(CAUSAL && j * BKV > wq0 + QT * 16 - 1 + coff); };
-    // Online-softmax bookkeeping of one 32-key half: mask (diagonal / ragged tiles only), row max, and the RARE rescale.
-    // The running max is only advanced when some row's max grew by more than 2^kDefer (in the exp2 domain): otherwise the
-    // probabilities of this half are taken against the old max (they are then bounded by 2^kDefer instead of 1, harmless in
-    // fp32 / bf16 and invisible in O = sum(P V) / sum(P)), and neither O nor the row sums need the multiply.  Returns the
-    // exponent offsets.  Everything that follows (exp2 + bf16 pack) is branch-free, so the compiler interleaves it with the
-    // MFMAs of the next group.
-    constexpr float kDefer = 6.0f;
-    auto max_half = [&](f32x4 (&s)[2][QT], int kbase_idx, bool need_mask, float (&nm)[QT], bf16x8 (*pending)[QT]) {
+        auto dma_tile = [&](int row0, int buf) {
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-            if (need_mask) {
-                const int qidx = wq0 + qt * 16 + t;
+            for (int i = 0; i < NDMA; ++i) {
+                const int grp = wave * NDMA + i;
+                const int row = min(row0 + grp * RPG + drow, sk_len - 1);  // rows past the end: any finite data (masked later)
+                GLDS16_(kbase + (int64_t)row * P.k_ss + k_src_chunk[i] * 8, Kb0 + buf * TILE + grp * 1024);
+                GLDS16_(vbase + (int64_t)row * P.k_ss + v_src_chunk[i] * 8, Vb0 + buf * TILE + grp * 1024);
+            }
+        };
+        // a wave takes part in tile j iff one of its queries can see one of the tile's keys
+        auto active = [&](int j) { return (wq0 < sq_len) && !(CAUSAL && j * BKV > wq0 + QT * 16 - 1 + coff); };
+        // Online-softmax bookkeeping of one 32-key half: mask (diagonal / ragged tiles only), row max, and the RARE rescale.
+        // The running max is only advanced when some row's max grew by more than 2^kDefer (in the exp2 domain): otherwise the
+        // probabilities of this half are taken against the old max (they are then bounded by 2^kDefer instead of 1, harmless in
+        // fp32 / bf16 and invisible in O = sum(P V) / sum(P)), and neither O nor the row sums need the multiply.  Returns the
+        // exponent offsets.  Everything that follows (exp2 + bf16 pack) is branch-free, so the compiler interleaves it with the
+        // MFMAs of the next group.
+        constexpr float kDefer = 6.0f;
+        auto max_half = [&](f32x4 (&s)[2][QT], int kbase_idx, bool need_mask, float (&nm)[QT], bf16x8 (*pending)[QT]) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                if (need_mask) {
+                    const int qidx = wq0 + qt * 16 + t;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int kidx = kbase_idx + kt * 16 + g * 4 + r;
+                            const bool dead = kidx >= sk_len || (CAUSAL && kidx > qidx + coff);
+                            s[kt][qt][r] = dead ? -INFINITY : s[kt][qt][r];
+                        }
+                }
+                float mx = vmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
+                mx = vmax3(mx, s[0][qt][3], s[1][qt][0]);
+                mx = vmax3(mx, s[1][qt][1], s[1][qt][2]);
+                mx = vmax2(mx, s[1][qt][3]);
+                const float m_new = group_max4(mx, m_run[qt]);
+                if (__any((m_new - m_run[qt]) * sl2 > kDefer)) {  // wave-uniform, rare after the first tiles
+                    const float alpha = fast_exp2((m_run[qt] - m_new) * sl2);  // 0 while the old max is the finite "minus infinity"
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
+                    lacc[qt] *= alpha;
+                    // probabilities of the previous half were exponentiated against the OLD max and have not entered O / the row
+                    // sums yet: they take the same factor (everything still at the old scale is rescaled exactly once)
+                    if (pending != nullptr) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) (*pending)[qt][e] = (bf16)((float)(*pending)[qt][e] * alpha);
+                    }
+                    m_run[qt] = m_new;
+                }
+                nm[qt] = -m_run[qt] * sl2;  // a row that has seen no key yet: +huge, and exp2(-inf + huge) = 0
+            }
+        };
+        // exp2 + bf16 pack of elements [e0, e0 + n) of a half (element e: qt = e / 8, slot = e % 8; slot < 4 -> key tile 0 of the
+        // half).  The packed words are pinned with an empty asm at the point where they are produced: LLVM otherwise SINKS the
+        // whole exponential chain into the block of its first use (the P V MFMAs), i.e. behind the MFMAs it is meant to overlap.
+        auto exp_slice = [&](const f32x4 (&s)[2][QT], const float (&nm)[QT], bf16x8 (&pb)[QT], int e0, int n) {
+#pragma unroll
+            for (int e = e0; e < e0 + n; e += 2) {
+                const int qt = e >> 3, sl = e & 7;
+                bf16x2 w;
+                w[0] = (bf16)fast_exp2(fmaf(s[sl >> 2][qt][sl & 3], sl2, nm[qt]));
+                w[1] = (bf16)fast_exp2(fmaf(s[(sl + 1) >> 2][qt][(sl + 1) & 3], sl2, nm[qt]));
+                uint32_t u = __builtin_bit_cast(uint32_t, w);
+                asm volatile("" : "+v"(u));
+                w = __builtin_bit_cast(bf16x2, u);
+                pb[qt][sl] = w[0];
+                pb[qt][sl + 1] = w[1];
+            }
+        };
+        constexpr int NE = QT * 8;  // exp elements per half
+
+        // ---- the fragment stream of one tile: 32 steps = {K frags of keys 0..31} {K frags of keys 32..63} {V frags 0..31} {V frags
+        // 32..63}, DS*2 / DT steps each (D = 128: 8 / 8 / 8 / 8).  Every LDS read is inline asm, requested PRE steps ahead of its
+        // MFMAs and retired by a COUNTED s_waitcnt lgkmcnt(n) (LDS returns in order): with the compiler's own placement each step
+        // waited out a full LDS round trip (~200 cycles x 32 steps per tile -- the reason the 4-wave kernel ran its MFMAs 10 % of
+        // the time).  Steps are compile-time indices, so ring slots and immediates are static.
+        constexpr int NSK = DS * 2, NSV = DT;                 // steps per K half / per V half
+        constexpr int NSTEP = 2 * NSK + 2 * NSV;
+        constexpr int PRE = 5;                                // fragments in flight (<= 15 LDS operations outstanding)
+        constexpr int RING = PRE + 1;
+        u32x4 kring[RING];
+        u32x2 vlo[RING], vhi[RING];
+        // per-lane LDS byte addresses (tile buffer 0): K row image at (row t, chunk ds*4 + g), V col image at (row g*4 + t/4, d = 4*(t&3))
+        uint32_t kaddr0[DS];
+#pragma unroll
+        for (int ds = 0; ds < DS; ++ds) kaddr0[ds] = lds_addr32(Kb0 + Img::row_off(t, ds * 4 + g));
+        const uint32_t vaddr0 = lds_addr32(Vb0 + (g * 4 + (t >> 2)) * Img::PITCH + (t & 3) * 8);
+        const uint32_t vswz = (uint32_t)((D == 128 ? ((g * 4 + (t >> 2)) & 7) : (((g * 4 + (t >> 2)) >> 1) & 3)) << 5);
+        uint32_t kaddr[DS], vaddr = vaddr0;
+        auto frag_ops = [](int f) { return f < 2 * NSK ? 1 : 2; };  // LDS operations of fragment f
+        auto issue = [&kring, &vlo, &vhi, &kaddr, &vaddr, vswz](auto fc) {
+            constexpr int f = decltype(fc)::value;
+            if constexpr (f < 2 * NSK) {
+                constexpr int hh = f / NSK, ds = (f % NSK) >> 1, kt = (f % NSK) & 1;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kring[f % RING]) : "v"(kaddr[ds]), "n"((2 * hh + kt) * 16 * Img::PITCH));
+            } else {
+                constexpr int hh = (f - 2 * NSK) / NSV, dt = (f - 2 * NSK) % NSV;
+                const uint32_t a = vaddr + ((uint32_t)(dt << 5) ^ vswz);
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[f % RING]) : "v"(a), "n"((2 * hh) * 16 * Img::PITCH));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[f % RING]) : "v"(a), "n"((2 * hh + 1) * 16 * Img::PITCH));
+            }
+        };
+        auto wait_frag = [&kring, &vlo, &vhi](auto fc) {  // retire fragment f: everything requested after it may stay in flight
+            constexpr int f = decltype(fc)::value;
+            constexpr int last = f + PRE < NSTEP ? f + PRE : NSTEP - 1;
+            constexpr int younger = [](int f0, int l0) { int n = 0; for (int i = f0 + 1; i <= l0; ++i) n += (i < 2 * (D / 32) * 2 ? 1 : 2); return n; }(f, last);
+            static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
+            if constexpr (f < 2 * NSK)
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kring[f % RING]) : "n"(younger) : "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(vlo[f % RING]), "+v"(vhi[f % RING]) : "n"(younger) : "memory");
+        };
+        (void)frag_ops;
+
+        // ---- prologue: tile 0 -> LDS
+        if (nblk > 0) dma_tile(0, 0);
+        __syncthreads();
+
+        for (int j = 0; j < nblk; ++j) {
+            const int kv0 = j * BKV;
+            if (j + 1 < nblk) dma_tile(kv0 + BKV, (j + 1) & 1);  // the next tile flies under this tile's compute
+            if (active(j)) {
+                const uint32_t boff = (uint32_t)((j & 1) * TILE);
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) kaddr[ds] = kaddr0[ds] + boff;
+                vaddr = vaddr0 + boff;
+                const bool need_mask = (kv0 + BKV > sk_len) || (CAUSAL && (kv0 + BKV - 1 > wq0 + coff));
+                f32x4 sa[2][QT], sb[2][QT];
+                bf16x8 pa[QT], pbb[QT];
+                float nma[QT], nmb[QT];
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kidx = kbase_idx + kt * 16 + g * 4 + r;
-                        const bool dead = kidx >= sk_len || (CAUSAL && kidx > qidx + coff);
-                        s[kt][qt][r] = dead ? -INFINITY : s[kt][qt][r];
-                    }
-            }
-            float mx = vmax3(s[0][qt][0], s[0][qt][1], s[0][qt][2]);
-            mx = vmax3(mx, s[0][qt][3], s[1][qt][0]);
-            mx = vmax3(mx, s[1][qt][1], s[1][qt][2]);
-            mx = vmax2(mx, s[1][qt][3]);
-            const float m_new = group_max4(mx, m_run[qt]);
-            if (__any((m_new - m_run[qt]) * sl2 > kDefer)) {  // wave-uniform, rare after the first tiles
-                const float alpha = fast_exp2((m_run[qt] - m_new) * sl2);  // 0 while the old max is the finite "minus infinity"
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) oacc[dt][qt] *= alpha;
-                lacc[qt] *= alpha;
-                // probabilities of the previous half were exponentiated against the OLD max and have not entered O / the row
-                // sums yet: they take the same factor (everything still at the old scale is rescaled exactly once)
-                if (pending != nullptr) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) (*pending)[qt][e] = (bf16)((float)(*pending)[qt][e] * alpha);
-                }
-                m_run[qt] = m_new;
-            }
-            nm[qt] = -m_run[qt] * sl2;  // a row that has seen no key yet: +huge, and exp2(-inf + huge) = 0
-        }
-    };
-    // exp2 + bf16 pack of elements [e0, e0 + n) of a half (element e: qt = e / 8, slot = e % 8; slot < 4 -> key tile 0 of the
-    // half).  The packed words are pinned with an empty asm at the point where they are produced: LLVM otherwise SINKS the
-    // whole exponential chain into the block of its first use (the P V MFMAs), i.e. behind the MFMAs it is meant to overlap.
-    auto exp_slice = [&](const f32x4 (&s)[2][QT], const float (&nm)[QT], bf16x8 (&pb)[QT], int e0, int n) {
-#pragma unroll
-        for (int e = e0; e < e0 + n; e += 2) {
-            const int qt = e >> 3, sl = e & 7;
-            bf16x2 w;
-            w[0] = (bf16)fast_exp2(fmaf(s[sl >> 2][qt][sl & 3], sl2, nm[qt]));
-            w[1] = (bf16)fast_exp2(fmaf(s[(sl + 1) >> 2][qt][(sl + 1) & 3], sl2, nm[qt]));
-            uint32_t u = __builtin_bit_cast(uint32_t, w);
-            asm volatile("" : "+v"(u));
-            w = __builtin_bit_cast(bf16x2, u);
-            pb[qt][sl] = w[0];
-            pb[qt][sl + 1] = w[1];
-        }
-    };
-    constexpr int NE = QT * 8;  // exp elements per half
-
-    // ---- the fragment stream of one tile: 32 steps = {K frags of keys 0..31} {K frags of keys 32..63} {V frags 0..31} {V frags
-    // 32..63}, DS*2 / DT steps each (D = 128: 8 / 8 / 8 / 8).  Every LDS read is inline asm, requested PRE steps ahead of its
-    // MFMAs and retired by a COUNTED s_waitcnt lgkmcnt(n) (LDS returns in order): with the compiler's own placement each step
-    // waited out a full LDS round trip (~200 cycles x 32 steps per tile -- the reason the 4-wave kernel ran its MFMAs 10 % of
-    // the time).  Steps are compile-time indices, so ring slots and immediates are static.
-    constexpr int NSK = DS * 2, NSV = DT;                 // steps per K half / per V half
-    constexpr int NSTEP = 2 * NSK + 2 * NSV;
-    constexpr int PRE = 5;                                // fragments in flight (<= 15 LDS operations outstanding)
-    constexpr int RING = PRE + 1;
-    u32x4 kring[RING];
-    u32x2 vlo[RING], vhi[RING];
-    // per-lane LDS byte addresses (tile buffer 0): K row image at (row t, chunk ds*4 + g), V col image at (row g*4 + t/4, d = 4*(t&3))
-    uint32_t kaddr0[DS];
-#pragma unroll
-    for (int ds = 0; ds < DS; ++ds) kaddr0[ds] = lds_addr32(Kb0 + Img::row_off(t, ds * 4 + g));
-    const uint32_t vaddr0 = lds_addr32(Vb0 + (g * 4 + (t >> 2)) * Img::PITCH + (t & 3) * 8);
-    const uint32_t vswz = (uint32_t)((D == 128 ? ((g * 4 + (t >> 2)) & 7) : (((g * 4 + (t >> 2)) >> 1) & 3)) << 5);
-    uint32_t kaddr[DS], vaddr = vaddr0;
-    auto frag_ops = [](int f) { return f < 2 * NSK ? 1 : 2; };  // LDS operations of fragment f
-    auto issue = [&kring, &vlo, &vhi, &kaddr, &vaddr, vswz](auto fc) {
-        constexpr int f = decltype(fc)::value;
-        if constexpr (f < 2 * NSK) {
-            constexpr int hh = f / NSK, ds = (f % NSK) >> 1, kt = (f % NSK) & 1;
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kring[f % RING]) : "v"(kaddr[ds]), "n"((2 * hh + kt) * 16 * Img::PITCH));
-        } else {
-            constexpr int hh = (f - 2 * NSK) / NSV, dt = (f - 2 * NSK) % NSV;
-            const uint32_t a = vaddr + ((uint32_t)(dt << 5) ^ vswz);
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[f % RING]) : "v"(a), "n"((2 * hh) * 16 * Img::PITCH));
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[f % RING]) : "v"(a), "n"((2 * hh + 1) * 16 * Img::PITCH));
-        }
-    };
-    auto wait_frag = [&kring, &vlo, &vhi](auto fc) {  // retire fragment f: everything requested after it may stay in flight
-        constexpr int f = decltype(fc)::value;
-        constexpr int last = f + PRE < NSTEP ? f + PRE : NSTEP - 1;
-        constexpr int younger = [](int f0, int l0) { int n = 0; for (int i = f0 + 1; i <= l0; ++i) n += (i < 2 * (D / 32) * 2 ? 1 : 2); return n; }(f, last);
-        static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
-        if constexpr (f < 2 * NSK)
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kring[f % RING]) : "n"(younger) : "memory");
-        else
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(vlo[f % RING]), "+v"(vhi[f % RING]) : "n"(younger) : "memory");
-    };
-    (void)frag_ops;
-
-    // ---- prologue: tile 0 -> LDS
-    if (nblk > 0) dma_tile(0, 0);
-    __syncthreads();
-
-    for (int j = 0; j < nblk; ++j) {
-        const int kv0 = j * BKV;
-        if (j + 1 < nblk) dma_tile(kv0 + BKV, (j + 1) & 1);  // the next tile flies under this tile's compute
-        if (active(j)) {
-            const uint32_t boff = (uint32_t)((j & 1) * TILE);
-#pragma unroll
-            for (int ds = 0; ds < DS; ++ds) kaddr[ds] = kaddr0[ds] + boff;
-            vaddr = vaddr0 + boff;
-            const bool need_mask = (kv0 + BKV > sk_len) || (CAUSAL && (kv0 + BKV - 1 > wq0 + coff));
-            f32x4 sa[2][QT], sb[2][QT];
-            bf16x8 pa[QT], pbb[QT];
-            float nma[QT], nmb[QT];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int qt = 0; qt < QT; ++qt) {
-                    sa[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    sb[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            static_for_<0, PRE>([&](auto fc) { issue(fc); });
-            static_for_<0, NSTEP>([&](auto sc) {
-                constexpr int st = decltype(sc)::value;
-                if constexpr (st + PRE < NSTEP) issue(std::integral_constant<int, st + PRE>{});
-                // segment boundaries: the short VALU-only bookkeeping of the online softmax
-                if constexpr (st == NSK) max_half(sa, kv0, need_mask, nma, nullptr);
-                if constexpr (st == 2 * NSK) max_half(sb, kv0 + 32, need_mask, nmb, &pa);
-                if constexpr (st == 2 * NSK || st == 2 * NSK + NSV) {  // row sums of the half entering P V, on the matrix pipe
-#pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, st == 2 * NSK ? pa[qt] : pbb[qt], lacc[qt], 0, 0, 0);
-                }
-                wait_frag(sc);
-                if constexpr (st < 2 * NSK) {
-                    constexpr int hh = st / NSK, ds = (st % NSK) >> 1, kt = (st % NSK) & 1;
-                    const bf16x8 kf = __builtin_bit_cast(bf16x8, kring[st % RING]);
-#pragma unroll
                     for (int qt = 0; qt < QT; ++qt) {
-                        if constexpr (hh == 0)
-                            sa[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], sa[kt][qt], 0, 0, 0);
-                        else
-                            sb[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], sb[kt][qt], 0, 0, 0);
+                        sa[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        sb[kt][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
-                    // keys 32..63: under the exponentials of keys 0..31
-                    if constexpr (hh == 1) exp_slice(sa, nma, pa, (st - NSK) * NE / NSK, NE / NSK);
-                } else {
-                    constexpr int hh = (st - 2 * NSK) / NSV, dt = (st - 2 * NSK) % NSV;
-                    const bf16x8 va = join2(vlo[st % RING], vhi[st % RING]);
+                static_for_<0, PRE>([&](auto fc) { issue(fc); });
+                static_for_<0, NSTEP>([&](auto sc) {
+                    constexpr int st = decltype(sc)::value;
+                    if constexpr (st + PRE < NSTEP) issue(std::integral_constant<int, st + PRE>{});
+                    // segment boundaries: the short VALU-only bookkeeping of the online softmax
+                    if constexpr (st == NSK) max_half(sa, kv0, need_mask, nma, nullptr);
+                    if constexpr (st == 2 * NSK) max_half(sb, kv0 + 32, need_mask, nmb, &pa);
+                    if constexpr (st == 2 * NSK || st == 2 * NSK + NSV) {  // row sums of the half entering P V, on the matrix pipe
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt)
-                        oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, hh == 0 ? pa[qt] : pbb[qt], oacc[dt][qt], 0, 0, 0);
-                    // P V of keys 0..31: under the exponentials of keys 32..63
-                    if constexpr (hh == 0) exp_slice(sb, nmb, pbb, dt * NE / NSV, NE / NSV);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-        }
-        __syncthreads();  // tile j + 1 has landed (vmcnt(0) of the DMA) and every wave is done reading tile j
-    }
-
-    // finalize: lane holds O^T[d = dt*16 + g*4 + r][q = t] of tile qt; every row of lacc holds the row sum of query t
+                        for (int qt = 0; qt < QT; ++qt)
+                            lacc[qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, st == 2 * NSK ? pa[qt] : pbb[qt], lacc[qt], 0, 0, 0);
+                    }
+                    wait_frag(sc);
+                    if constexpr (st < 2 * NSK) {
+                        constexpr int hh = st / NSK, ds = (st % NSK) >> 1, kt = (st % NSK) & 1;
+                        const bf16x8 kf = __builtin_bit_cast(bf16x8, kring[st % RING]);
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-        const float l = lacc[qt][0];
-        const int qrow = wq0 + qt * 16 + t;
-        const bool valid = qrow < sq_len;
-        const float inv = (l > 0.f && valid) ? 1.0f / l : 0.f;
-        if (qrow < SqE) {
+                        for (int qt = 0; qt < QT; ++qt) {
+                            if constexpr (hh == 0)
+                                sa[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], sa[kt][qt], 0, 0, 0);
+                            else
+                                sb[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qt][ds], sb[kt][qt], 0, 0, 0);
+                        }
+                        // keys 32..63: under the exponentials of keys 0..31
+                        if constexpr (hh == 1) exp_slice(sa, nma, pa, (st - NSK) * NE / NSK, NE / NSK);
+                    } else {
+                        constexpr int hh = (st - 2 * NSK) / NSV, dt = (st - 2 * NSK) % NSV;
+                        const bf16x8 va = join2(vlo[st % RING], vhi[st % RING]);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                bf16x4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (bf16)(oacc[dt][qt][r] * inv);
-                st_bf16x4(obase + (int64_t)qrow * P.o_ss + dt * 16 + g * 4, o);
+                        for (int qt = 0; qt < QT; ++qt)
+                            oacc[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, hh == 0 ? pa[qt] : pbb[qt], oacc[dt][qt], 0, 0, 0);
+                        // P V of keys 0..31: under the exponentials of keys 32..63
+                        if constexpr (hh == 0) exp_slice(sb, nmb, pbb, dt * NE / NSV, NE / NSV);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
             }
-            if (lsebase && g == 0) lsebase[qrow] = (valid && l > 0.f) ? (m_run[qt] * P.scale + logf(l)) : 0.f;
+            __syncthreads();  // tile j + 1 has landed (vmcnt(0) of the DMA) and every wave is done reading tile j
         }
-    }
+
+        // finalize: lane holds O^T[d = dt*16 + g*4 + r][q = t] of tile qt; every row of lacc holds the row sum of query t
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const float l = lacc[qt][0];
+            const int qrow = wq0 + qt * 16 + t;
+            const bool valid = qrow < sq_len;
+            const float inv = (l > 0.f && valid) ? 1.0f / l : 0.f;
+            if (qrow < SqE) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = (bf16)(oacc[dt][qt][r] * inv);
+                    st_bf16x4(obase + (int64_t)qrow * P.o_ss + dt * 16 + g * 4, o);
+                }
+                if (lsebase && g == 0) lsebase[qrow] = (valid && l > 0.f) ? (m_run[qt] * P.scale + logf(l)) : 0.f;
+            }
+        }
+    }  // pass
 }
 
 template <int D, bool CAUSAL>
@@ -594,7 +601,8 @@ int launch_fwd8(const AttnParams& P, hipStream_t stream) {
     constexpr int LDS = 4 * 64 * D * 2;
     static std::atomic<uint64_t> lds_ok{0};
     dllm_ensure_dyn_lds(&attn_fwd8_kernel<D, CAUSAL>, LDS, lds_ok);
-    const dim3 grid(attn_grid((P.Sq + 255) / 256, P.H, P.B));
+    const int nqb = (P.Sq + 255) / 256;
+    const dim3 grid(attn_grid(CAUSAL ? (nqb + 1) / 2 : nqb, P.H, P.B));  // causal: one group per pair of query blocks
     hipLaunchKernelGGL((attn_fwd8_kernel<D, CAUSAL>), grid, dim3(512), LDS, stream, P);
     return dllm_check_launch();
 }
