@@ -370,18 +370,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
         constexpr int NS = 2 * DS;        // steps per segment (= DT)
         constexpr int NSTEP = 6 * NS;
         constexpr int PRE = 4, RING = PRE + 1;
-        u32x4 ring[RING];
-        u32x2 rlo[RING], rhi[RING];
-        uint32_t raddr0[DS], raddr[DS];   // row fragments: (row t, chunk ds*4 + g) of the unified image, K buffer 0
+        u32x4 ring[RING];  // one ring for both fragment kinds: a column fragment = two transpose reads composed into one register quad
+        uint32_t raddr[DS];   // row fragments: (row t, chunk ds*4 + g) of the unified image; start at buffer 0, toggled per tile
 #pragma unroll
-        for (int ds = 0; ds < DS; ++ds) raddr0[ds] = lds_addr32(Kb0 + t * PITCH + (((ds * 4 + g) ^ uni_f<D>(t)) << 4));
+        for (int ds = 0; ds < DS; ++ds) raddr[ds] = lds_addr32(Kb0 + t * PITCH + (((ds * 4 + g) ^ uni_f<D>(t)) << 4));
         // column fragments: row rr = g*4 + t/4, 8 bytes at d = dt*16 + 4*(t&3): chunk dt*2 + ((t>>1)&1), byte (t&1)*8
         const int rr = g * 4 + (t >> 2);
-        const uint32_t caddr0 = lds_addr32(Kb0 + rr * PITCH + (t & 1) * 8 + ((((t >> 1) & 1) ^ (uni_f<D>(rr) & 1)) << 4));
+        uint32_t caddr = lds_addr32(Kb0 + rr * PITCH + (t & 1) * 8 + ((((t >> 1) & 1) ^ (uni_f<D>(rr) & 1)) << 4));
         const uint32_t cswz = (uint32_t)((uni_f<D>(rr) >> 1) << 5);
-        uint32_t caddr = caddr0;
         auto is_col = [](int f) { return f >= 4 * (2 * (D / 32)); };
-        auto issue = [&ring, &rlo, &rhi, &raddr, &caddr, cswz](auto fc) {
+        auto issue = [&ring, &raddr, &caddr, cswz](auto fc) {
             constexpr int f = decltype(fc)::value;
             constexpr int seg = f / NS, i = f % NS;
             if constexpr (seg < 4) {  // K (even i) or V row fragment of key tile seg, d step i / 2: four accumulator chains in rotation
@@ -390,19 +388,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
             } else {                  // K column fragment of d tile i, keys of half seg - 4
                 constexpr int ks = seg - 4;
                 const uint32_t a = caddr + ((uint32_t)(i << 5) ^ cswz);
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(rlo[f % RING]) : "v"(a), "n"((2 * ks) * 16 * PITCH));
-                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(rhi[f % RING]) : "v"(a), "n"((2 * ks + 1) * 16 * PITCH));
+                u32x2 lo, hi;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"((2 * ks) * 16 * PITCH));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"((2 * ks + 1) * 16 * PITCH));
+                ring[f % RING] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
         };
-        auto wait_frag = [&ring, &rlo, &rhi](auto fc) {
+        auto wait_frag = [&ring](auto fc) {
             constexpr int f = decltype(fc)::value;
             constexpr int last = f + PRE < NSTEP ? f + PRE : NSTEP - 1;
             constexpr int younger = [](int f0, int l0) { int n = 0; for (int i = f0 + 1; i <= l0; ++i) n += (i < 8 * (D / 32) ? 1 : 2); return n; }(f, last);
             static_assert(younger <= 15, "lgkmcnt is a 4-bit counter");
-            if constexpr (f < 4 * NS)
-                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[f % RING]) : "n"(younger) : "memory");
-            else
-                asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(rlo[f % RING]), "+v"(rhi[f % RING]) : "n"(younger) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[f % RING]) : "n"(younger) : "memory");
         };
         (void)is_col;
 
@@ -413,10 +410,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
             const int kv0 = j * BKV;
             if (j + 1 < nblk) dma_tile(kv0 + BKV, (j + 1) & 1);
             if (active(j)) {
-                const uint32_t boff = (uint32_t)((j & 1) * TILE);
-#pragma unroll
-                for (int ds = 0; ds < DS; ++ds) raddr[ds] = raddr0[ds] + boff;
-                caddr = caddr0 + boff;
                 const bool need_mask = (kv0 + BKV > sk_len) || (CAUSAL && (kv0 + BKV - 1 > wq0 + coff));
                 f32x4 s[2][QT], dp[2][QT];   // scores / dP - delta of the key tile being accumulated and of the previous one
                 bf16x8 dsb[QT][2];           // dS^T as B operands: [k = 32 keys of half ks][n = query]
@@ -479,7 +472,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
                         }
                     } else {
                         constexpr int ks = seg - 4;
-                        const bf16x8 a = join2(rlo[st % RING], rhi[st % RING]);
+                        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[st % RING]);
 #pragma unroll
                         for (int qt = 0; qt < QT; ++qt)
                             dqacc[i][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsb[qt][ks], dqacc[i][qt], 0, 0, 0);
@@ -489,6 +482,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }
+#pragma unroll
+            for (int ds = 0; ds < DS; ++ds) raddr[ds] ^= (uint32_t)TILE;  // the other K / V buffer (dynamic LDS starts at address 0)
+            caddr ^= (uint32_t)TILE;
             __syncthreads();
         }
 
@@ -1048,7 +1044,7 @@ int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_
     if (wide_dq) {
         dllm_ensure_dyn_lds(&attn_bwd_dq8_kernel<D, CAUSAL>, LDS_DQ, lds3_ok);
         const int nqb8 = (P.Sq + 255) / 256;  // causal: one group per pair of row blocks
-        hipLaunchKernelGGL((attn_bwd_dq8_kernel<D, CAUSAL>), dim3(attn_grid(CAUSAL ? (nqb8 + 1) / 2 : nqb8, P.H, P.B)), dim3(512), LDS_DQ, stream, P);
+                hipLaunchKernelGGL((attn_bwd_dq8_kernel<D, CAUSAL>), dim3(attn_grid(CAUSAL ? (nqb8 + 1) / 2 : nqb8, P.H, P.B)), dim3(512), LDS_DQ, stream, P);
     } else {
         dllm_ensure_dyn_lds(&attn_bwd_dq_kernel<D, CAUSAL, QT>, LDS_DQ, lds_ok);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<D, CAUSAL, QT>), dim3(attn_grid((P.Sq + BQ - 1) / BQ, P.H, P.B)), dim3(256), LDS_DQ, stream, P);

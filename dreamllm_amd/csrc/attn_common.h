@@ -181,7 +181,8 @@ struct AttnBlock {
 // Causal 8-wave kernels do not hand out single row blocks at all: a work-group takes the PAIR (heaviest remaining, lightest
 // remaining) = (nrb-1-r, r), so every group does the same number of key tiles.  (An LPT order -- an XCD walks the row blocks of
 // ALL its heads heaviest first -- balanced the tail as well, +8 %, but gave up the L2 sharing between a head's blocks; pairing
-// gives both, another +5...10 %.)
+// gives both, another +5...10 %.  With pairing, dealing consecutive groups of an XCD to DIFFERENT heads instead of head-major
+// measured 4-9 % slower on every kernel.)
 template <bool UNUSED = false>
 __device__ __forceinline__ AttnBlock attn_block_map(int nrow_blocks, int heads, int B) {
     const int L = blockIdx.x;
