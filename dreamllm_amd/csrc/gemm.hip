@@ -1156,8 +1156,8 @@ static inline double tile_eff(int64_t M, int64_t N, int T, double speed) {
 // Three-way choice when the pipelined kernels are eligible: estimated time = rounds x (fixed + K tiles x per-K-tile cost) with the
 // per-round figures measured on the UNet conv shapes (tools/microbench.py --only conv --tile {128,259,262}; microseconds):
 // 256 x 256 pipelined 9 + 1.9 k, 256 x 128 pipelined 6 + 1.3 k (0.69 of the big tile's time for half its outputs), 128 x 128
-// register-staged 6 + 1.75 k with two blocks per CU.  Only grids that fill the chip are compared (smaller ones are split-K or
-// keep the padding-based choice above).
+// register-staged 6 + 1.75 k with two blocks per CU.  Only grids of at least 128 of the 256 x 128 tiles are compared (smaller
+// ones are split-K or keep the padding-based choice above).
 static inline double tile_cost_us(int64_t M, int64_t N, int64_t K, int TM, int TN, int64_t slots, double fixed, double perk) {
     const int64_t tiles = cdiv64(M, TM) * cdiv64(N, TN);
     return (double)cdiv64(tiles, slots) * (fixed + (double)K / 64.0 * perk);
@@ -1176,7 +1176,7 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     if constexpr (BL == B_K && (AL == A_K || AL == A_CONV)) {
         // narrow outputs (N = 320: 62 % of two 256-wide tiles, 83 % of three 128-wide ones): the pipelined kernel on 256 x 128 tiles
         bool n128 = V.force_n128 != 0;
-        if (!n128 && V.force_tile == 0 && glds_ok && cdiv64(P.M, 256) * cdiv64(P.N, 128) >= 256) {
+        if (!n128 && V.force_tile == 0 && glds_ok && cdiv64(P.M, 256) * cdiv64(P.N, 128) >= 128) {  // at least half the CUs
             const double c256 = tile_cost_us(P.M, P.N, P.K, 256, 256, 256, 9.0, 1.9);
             const double cn = tile_cost_us(P.M, P.N, P.K, 256, 128, 256, 6.0, 1.3);
             const double c128 = tile_cost_us(P.M, P.N, P.K, 128, 128, 512, 6.0, 1.75);
