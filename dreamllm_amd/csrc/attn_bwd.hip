@@ -3,13 +3,16 @@
 // Replaces the autograd of modeling_dreamllm.py:357-379 / flash_attn's backward behind modeling_dreamllm.py:532-549
 // and the attention backward inside the frozen UNet (dgrad only) [ext].
 //
-// Three launches, no atomics, deterministic:
+// No atomics, deterministic.  Two kernel families (chosen per call like the forward's):
+//   4-wave kernels (short axes):
 //   1. delta[b,h,q] = sum_d dO * O                                   (HBM-bound preprocess)
 //   2. dQ  : block = 4 waves x (QT*16) queries, loops over KV blocks; recomputes S^T = K Q^T and dP^T = V dO^T with
 //            K and V tiles in LDS; dQ^T += K^T dS^T reads the same K tile through transpose reads.
 //   3. dK,dV: block = 4 waves x (KT*16) keys held in registers, loops over Q blocks (and over the query heads of a
 //            GQA group); recomputes S = Q K^T and dP = dO V^T from Q / dO tiles in LDS, then dV^T += dO^T P and
 //            dK^T += Q^T dS read the same tiles through transpose reads.
+//   8-wave pipelined kernels (axes >= 512): attn_bwd_dq8_kernel (computes delta itself and publishes the statistic planes),
+//   then attn_bwd_dkv8_kernel (fused at head_dim 64, split into a dK and a dV pass at head_dim 128); see their headers below.
 // P = exp(scale*S - LSE) uses the forward's saved log-sum-exp; dS = P * (dP - delta).
 #include "attn_common.h"
 
@@ -308,19 +311,35 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
         {
             const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
             const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh + (int64_t)sp.qst * P.o_ss;
-            const float* lsep = P.lse + ((int64_t)b * P.H + h) * P.Sq + sp.qst;
-            const float* dlp = P.delta + ((int64_t)b * P.H + h) * P.Sq + sp.qst;
+            const bf16* obase = P.o + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh + (int64_t)sp.qst * P.o_ss;
+            const int64_t stat0 = ((int64_t)b * P.H + h) * P.Sq + sp.qst, plane = (int64_t)P.B * P.H * P.Sq;
+            const float* lsep = P.lse + stat0;
+            // delta = rowsum(dO * O) is computed HERE (this is the first backward kernel; no separate preprocess launch): a lane
+            // holds 32 of its row's d values per operand, the other three quarters sit in lanes t+16, t+32, t+48.  The three
+            // statistic planes of the workspace (delta, -delta, -lse/scale) are published for the dK / dV kernels that follow.
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 const int qrow = wq0 + qt * 16 + t;
                 const bool ok = qrow < sq_len;  // rows past the end: all-zero operands => S = 0, P = 1, dP - delta = 0, dS = 0
+                float dsum = 0.f;
 #pragma unroll
                 for (int ds = 0; ds < DS; ++ds) {
                     qf[qt][ds] = ok ? ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8) : zero_bf16x8();
                     dof[qt][ds] = ok ? ld_bf16x8(dobase + (int64_t)qrow * P.o_ss + ds * 32 + g * 8) : zero_bf16x8();
+                    const bf16x8 of = ok ? ld_bf16x8(obase + (int64_t)qrow * P.o_ss + ds * 32 + g * 8) : zero_bf16x8();
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dsum += (float)of[e] * (float)dof[qt][ds][e];
                 }
-                nlse2[qt] = ok ? -lsep[qrow] * kLog2e : 0.f;
-                ndlt[qt] = ok ? -dlp[qrow] : 0.f;
+                dsum += __shfl_xor(dsum, 16, 64);
+                dsum += __shfl_xor(dsum, 32, 64);
+                const float lse = ok ? lsep[qrow] : 0.f;
+                nlse2[qt] = -lse * kLog2e;
+                ndlt[qt] = -dsum;
+                if (ok && g == 0) {
+                    P.delta[stat0 + qrow] = dsum;
+                    P.delta[plane + stat0 + qrow] = -dsum;
+                    P.delta[2 * plane + stat0 + qrow] = -lse / P.scale;
+                }
             }
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
@@ -1039,7 +1058,8 @@ int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_
     static std::atomic<uint64_t> lds_ok{0}, lds2_ok{0}, lds3_ok{0}, lds4_ok{0}, lds5_ok{0};
     const int64_t rows = (int64_t)P.B * P.Sq * P.H;
     const int64_t nthreads = rows * (D / 8);
-    hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, P);
+    if (!wide_dq)  // the 8-wave dQ kernel computes delta and publishes the statistic planes itself
+        hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, P);
     constexpr int BQ = 4 * QT * 16, BKEYS = 4 * KT * 16;
     if (wide_dq) {
         dllm_ensure_dyn_lds(&attn_bwd_dq8_kernel<D, CAUSAL>, LDS_DQ, lds3_ok);
