@@ -410,7 +410,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
                 u32x2 lo, hi;
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a), "n"((2 * ks) * 16 * PITCH));
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a), "n"((2 * ks + 1) * 16 * PITCH));
-                ring[f % RING] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+                // NOTE: the quad is composed right after the two transpose reads are ISSUED, i.e. before their data has arrived: this
+            // is correct only because hipcc coalesces lo / hi into the sub-registers of the quad (no v_mov is emitted; the
+            // counted s_waitcnt in wait_frag() pins the quad).  Copies here would read registers still in flight -- every
+            // attention test would fail, which is the guard.
+            ring[f % RING] = u32x4{lo[0], lo[1], hi[0], hi[1]};
             }
         };
         auto wait_frag = [&ring](auto fc) {
