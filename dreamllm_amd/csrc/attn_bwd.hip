@@ -306,52 +306,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
             continue;
         }
 
-        bf16x8 qf[QT][DS], dof[QT][DS];
-        float nlse2[QT], ndlt[QT];
-        {
-            const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
-            const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh + (int64_t)sp.qst * P.o_ss;
-            const bf16* obase = P.o + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh + (int64_t)sp.qst * P.o_ss;
-            const int64_t stat0 = ((int64_t)b * P.H + h) * P.Sq + sp.qst, plane = (int64_t)P.B * P.H * P.Sq;
-            const float* lsep = P.lse + stat0;
-            // delta = rowsum(dO * O) is computed HERE (this is the first backward kernel; no separate preprocess launch): a lane
-            // holds 32 of its row's d values per operand, the other three quarters sit in lanes t+16, t+32, t+48.  The three
-            // statistic planes of the workspace (delta, -delta, -lse/scale) are published for the dK / dV kernels that follow.
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const int qrow = wq0 + qt * 16 + t;
-                const bool ok = qrow < sq_len;  // rows past the end: all-zero operands => S = 0, P = 1, dP - delta = 0, dS = 0
-                float dsum = 0.f;
-#pragma unroll
-                for (int ds = 0; ds < DS; ++ds) {
-                    qf[qt][ds] = ok ? ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8) : zero_bf16x8();
-                    dof[qt][ds] = ok ? ld_bf16x8(dobase + (int64_t)qrow * P.o_ss + ds * 32 + g * 8) : zero_bf16x8();
-                    const bf16x8 of = ok ? ld_bf16x8(obase + (int64_t)qrow * P.o_ss + ds * 32 + g * 8) : zero_bf16x8();
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) dsum += (float)of[e] * (float)dof[qt][ds][e];
-                }
-                dsum += __shfl_xor(dsum, 16, 64);
-                dsum += __shfl_xor(dsum, 32, 64);
-                const float lse = ok ? lsep[qrow] : 0.f;
-                nlse2[qt] = -lse * kLog2e;
-                ndlt[qt] = -dsum;
-                if (ok && g == 0) {
-                    P.delta[stat0 + qrow] = dsum;
-                    P.delta[plane + stat0 + qrow] = -dsum;
-                    P.delta[2 * plane + stat0 + qrow] = -lse / P.scale;
-                }
-            }
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-#pragma unroll
-                for (int ds = 0; ds < DS; ++ds) {
-                    pin_loaded(qf[qt][ds]);
-                    pin_loaded(dof[qt][ds]);
-                }
-                pin_loaded(nlse2[qt]);
-                pin_loaded(ndlt[qt]);
-            }
-        }
 
         int kv_end = sk_len;
         if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
@@ -427,6 +381,54 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
         (void)is_col;
 
         if (nblk > 0) dma_tile(0, 0);
+
+        // operand loads AFTER the first tile's DMA is in flight: the two latencies overlap instead of adding up
+        bf16x8 qf[QT][DS], dof[QT][DS];
+        float nlse2[QT], ndlt[QT];
+        {
+            const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
+            const bf16* dobase = P.dout + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh + (int64_t)sp.qst * P.o_ss;
+            const bf16* obase = P.o + (int64_t)b * P.o_sb + (int64_t)h * P.o_sh + (int64_t)sp.qst * P.o_ss;
+            const int64_t stat0 = ((int64_t)b * P.H + h) * P.Sq + sp.qst, plane = (int64_t)P.B * P.H * P.Sq;
+            const float* lsep = P.lse + stat0;
+            // delta = rowsum(dO * O) is computed HERE (this is the first backward kernel; no separate preprocess launch): a lane
+            // holds 32 of its row's d values per operand, the other three quarters sit in lanes t+16, t+32, t+48.  The three
+            // statistic planes of the workspace (delta, -delta, -lse/scale) are published for the dK / dV kernels that follow.
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int qrow = wq0 + qt * 16 + t;
+                const bool ok = qrow < sq_len;  // rows past the end: all-zero operands => S = 0, P = 1, dP - delta = 0, dS = 0
+                float dsum = 0.f;
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    qf[qt][ds] = ok ? ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8) : zero_bf16x8();
+                    dof[qt][ds] = ok ? ld_bf16x8(dobase + (int64_t)qrow * P.o_ss + ds * 32 + g * 8) : zero_bf16x8();
+                    const bf16x8 of = ok ? ld_bf16x8(obase + (int64_t)qrow * P.o_ss + ds * 32 + g * 8) : zero_bf16x8();
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dsum += (float)of[e] * (float)dof[qt][ds][e];
+                }
+                dsum += __shfl_xor(dsum, 16, 64);
+                dsum += __shfl_xor(dsum, 32, 64);
+                const float lse = ok ? lsep[qrow] : 0.f;
+                nlse2[qt] = -lse * kLog2e;
+                ndlt[qt] = -dsum;
+                if (ok && g == 0) {
+                    P.delta[stat0 + qrow] = dsum;
+                    P.delta[plane + stat0 + qrow] = -dsum;
+                    P.delta[2 * plane + stat0 + qrow] = -lse / P.scale;
+                }
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    pin_loaded(qf[qt][ds]);
+                    pin_loaded(dof[qt][ds]);
+                }
+                pin_loaded(nlse2[qt]);
+                pin_loaded(ndlt[qt]);
+            }
+        }
         __syncthreads();
 
         for (int j = 0; j < nblk; ++j) {
@@ -846,28 +848,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv8_kernel(AttnParams P) {
             dvbase += (int64_t)sp.kst * dk_ss;
         }
 
-        bf16x8 kfB[KT][DS], vfB[KT][DS];
-        {
-            const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
-            const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const int krow = wk0 + kt * 16 + t;
-                const bool ok = krow < sk_len;
-#pragma unroll
-                for (int ds = 0; ds < DS; ++ds) {
-                    kfB[kt][ds] = ok ? ld_bf16x8(kbase + (int64_t)krow * P.k_ss + ds * 32 + g * 8) : zero_bf16x8();
-                    if constexpr (kDK) vfB[kt][ds] = ok ? ld_bf16x8(vbase + (int64_t)krow * P.k_ss + ds * 32 + g * 8) : zero_bf16x8();
-                }
-            }
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int ds = 0; ds < DS; ++ds) {
-                    pin_loaded(kfB[kt][ds]);
-                    if constexpr (kDK) pin_loaded(vfB[kt][ds]);
-                }
-        }
         f32x4 dkacc[DT][KT], dvacc[DT][KT];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
@@ -948,6 +928,30 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv8_kernel(AttnParams P) {
         };
 
         if (niter > 0) dma_tile(0, 0);
+
+        // operand loads AFTER the first tile's DMA is in flight: the two latencies overlap instead of adding up
+        bf16x8 kfB[KT][DS], vfB[KT][DS];
+        {
+            const bf16* kbase = P.k + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+            const bf16* vbase = P.v + (int64_t)b * P.k_sb + (int64_t)hk * P.k_sh + (int64_t)sp.kst * P.k_ss;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const int krow = wk0 + kt * 16 + t;
+                const bool ok = krow < sk_len;
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    kfB[kt][ds] = ok ? ld_bf16x8(kbase + (int64_t)krow * P.k_ss + ds * 32 + g * 8) : zero_bf16x8();
+                    if constexpr (kDK) vfB[kt][ds] = ok ? ld_bf16x8(vbase + (int64_t)krow * P.k_ss + ds * 32 + g * 8) : zero_bf16x8();
+                }
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) {
+                    pin_loaded(kfB[kt][ds]);
+                    if constexpr (kDK) pin_loaded(vfB[kt][ds]);
+                }
+        }
         __syncthreads();
 
         for (int it = 0; it < niter; ++it) {

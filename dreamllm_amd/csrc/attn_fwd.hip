@@ -336,20 +336,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
             continue;
         }
 
-        bf16x8 qf[QT][DS];
-        {
-            const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt) {
-                const int qrow = min(wq0 + qt * 16 + t, sq_len - 1);
-#pragma unroll
-                for (int ds = 0; ds < DS; ++ds) qf[qt][ds] = ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8);
-            }
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                for (int ds = 0; ds < DS; ++ds) pin_loaded(qf[qt][ds]);
-        }
 
         int kv_end = sk_len;
         if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
@@ -514,6 +500,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
 
         // ---- prologue: tile 0 -> LDS
         if (nblk > 0) dma_tile(0, 0);
+
+        // operand loads AFTER the first tile's DMA is in flight: the two latencies overlap instead of adding up
+        bf16x8 qf[QT][DS];
+        {
+            const bf16* qbase = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int qrow = min(wq0 + qt * 16 + t, sq_len - 1);
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) qf[qt][ds] = ld_bf16x8(qbase + (int64_t)qrow * P.q_ss + ds * 32 + g * 8);
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int ds = 0; ds < DS; ++ds) pin_loaded(qf[qt][ds]);
+        }
         __syncthreads();
 
         for (int j = 0; j < nblk; ++j) {
