@@ -271,6 +271,7 @@ def main():
                           by_kind={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), launches=v[2] // max(a.steps, 1))
                                    for k, v in by_tag.items() if v[1] > 0}),
             e2e_frac_mfma_peak=None if tiny else round(value / world * FLOPS_TRAIN_SAMPLE / (PEAK_BF16_TFLOPS * 1e12), 4),
+            peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1),
         )
 
     # ------------------------------------------------------------------ the other BASELINE.json configs (N = 1 only, short)
@@ -309,10 +310,11 @@ def main():
                        "model": "dreamllm-7b" if not tiny else "tiny", "global_batch": world * a.batch, "per_gpu_batch": a.batch,
                        "seq_len": a.seq_len if not tiny else 512, "images_per_sample": a.images_per_sample,
                        "parallelism": f"dp{world}" + ("-shardedgrad" if (a.sharded_grad and world > 1) else ""), "optimizer": "AdamW bf16 states + global-norm clip 1.0",
-                       "activation_recompute": "RMSNorm/SwiGLU only (no layer checkpointing)"},
+                       "activation_recompute": "none (no layer checkpointing; normed inputs and the SwiGLU product are kept: +40 GB, peak_hbm_gb)"},
             "loss": train.get("loss"),
             "roofline": train.get("roofline"),
             "e2e_frac_mfma_peak": train.get("e2e_frac_mfma_peak"),
+            "peak_hbm_gb": train.get("peak_hbm_gb"),
             "denoise": denoise,
             "configs": configs,
         }

@@ -142,6 +142,12 @@ def pack_linear_weights(*linears):
         r += n
 
 
+# 288 GB of HBM per MI355X: the normed inputs of the two GEMM groups and the SwiGLU product (1.26 GB per layer, 40 GB for the 7B
+# model at B=16 x S=2048) are KEPT for the backward instead of recomputed (two RMSNorm passes and 0.7 GB of extra SwiGLU-backward
+# traffic per layer); peak 161 -> 201 GB.  Set to False to trade the 40 GB back for ~0.7 % of the step (larger models / batches).
+KEEP_LAYER_ACTIVATIONS = os.environ.get("DREAMLLM_KEEP_LAYER_ACTIVATIONS", "1") != "0"
+
+
 class _DecoderLayerFn(torch.autograd.Function):
     """DreamLLMDecoderLayer.forward (modeling_dreamllm.py:622-640) with a hand-written backward.
 
@@ -167,13 +173,16 @@ class _DecoderLayerFn(torch.autograd.Function):
             ops.gemm(h2d, wq, T, nq, Hd, Hd, Hd, 0, 0, out=o2d[:, :nq])
             ops.gemm(h2d, wk, T, nkv, Hd, Hd, Hd, 0, 0, out=o2d[:, nq:nq + nkv])
             ops.gemm(h2d, wv, T, nkv, Hd, Hd, Hd, 0, 0, out=o2d[:, nq + nkv:])
+        need_bwd = any(ctx.needs_input_grad[:10])
+        ng = ctx.needs_input_grad          # kept tensors only feed weight gradients (a frozen LLM keeps nothing extra)
+        keep = need_bwd and KEEP_LAYER_ACTIVATIONS
+        h_keep = h if (keep and (ng[2] or ng[3] or ng[4])) else None
         del h
         qk = qkv[:, :, : nq + nkv].unflatten(-1, (n_heads + n_kv, hd))   # q heads then k heads: one RoPE launch
         ops.rope_(qk, cos, sin, pos)
         q = qkv[:, :, :nq].unflatten(-1, (n_heads, hd))
         k = qkv[:, :, nq:nq + nkv].unflatten(-1, (n_kv, hd))
         v = qkv[:, :, nq + nkv:].unflatten(-1, (n_kv, hd))
-        need_bwd = any(ctx.needs_input_grad[:10])
         o, lse = ops.attn_fwd(q, k, v, True, 1.0 / math.sqrt(hd), seqlens, need_lse=need_bwd, seqstart=seqstart)
         x2 = ops.linear_fwd(o.view(B, S, Hd), wo, residual=x)
         h2, _, rstd2 = ops.rmsnorm_fwd(x2, w_post, eps)
@@ -186,12 +195,13 @@ class _DecoderLayerFn(torch.autograd.Function):
             h22 = h2.view(T, Hd)
             ops.gemm(h22, wg, T, F_, Hd, Hd, Hd, 0, 0, out=gu[:, :F_])
             ops.gemm(h22, wu, T, F_, Hd, Hd, Hd, 0, 0, out=gu[:, F_:])
+        h2_keep = h2 if (keep and (ng[7] or ng[8])) else None
         del h2
         act = ops.glu_fwd(gu[:, :F_], gu[:, F_:], 0)
         y = ops.linear_fwd(act.view(B, S, F_), wd, residual=x2)
         if need_bwd:
             ctx.save_for_backward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, qkv, o, lse,
-                                  x2, rstd2, gu)
+                                  x2, rstd2, gu, h_keep, h2_keep, act if (keep and ng[9]) else None)
             ctx.cfg = (n_heads, n_kv, eps)
         if want_kv:
             k, v = k.contiguous(), v.contiguous()  # the cache must not pin the packed q/k/v buffer
@@ -202,7 +212,7 @@ class _DecoderLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dk, _dv):
         (x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, qkv, o, lse, x2, rstd2,
-         gu) = ctx.saved_tensors
+         gu, h_keep, h2_keep, act_keep) = ctx.saved_tensors
         n_heads, n_kv, eps = ctx.cfg
         B, S, Hd = x.shape
         hd = Hd // n_heads
@@ -215,8 +225,11 @@ class _DecoderLayerFn(torch.autograd.Function):
         d_act = ops.linear_dgrad(dy, wd)
         g, u = gu[:, :F_], gu[:, F_:]
         dgu = torch.empty_like(gu)
-        act = torch.empty(T, F_, dtype=x.dtype, device=x.device) if need[9] else None
-        ops.glu_bwd(d_act, g, u, 0, da=dgu[:, :F_], db=dgu[:, F_:], act_out=act)  # dg, du AND the recomputed product in one pass
+        act = act_keep
+        if act is None and need[9]:
+            act = torch.empty(T, F_, dtype=x.dtype, device=x.device)
+        # dg, du (AND, when it was not kept, the recomputed product) in one pass
+        ops.glu_bwd(d_act, g, u, 0, da=dgu[:, :F_], db=dgu[:, F_:], act_out=None if act_keep is not None else act)
         del d_act
         dwd = None
         if need[9]:
@@ -225,7 +238,7 @@ class _DecoderLayerFn(torch.autograd.Function):
         wgu = _packed_view(wg, wu)
         dwg = dwu = None
         if need[7] or need[8]:
-            h2, _, _ = ops.rmsnorm_fwd(x2, w_post, eps)  # recomputed
+            h2 = h2_keep if h2_keep is not None else ops.rmsnorm_fwd(x2, w_post, eps)[0]  # kept, or recomputed
             if wgu is not None and need[7] and need[8]:
                 dwgu = ops.linear_wgrad(dgu, h2)
                 dwg, dwu = dwgu[:F_], dwgu[F_:]
@@ -259,7 +272,7 @@ class _DecoderLayerFn(torch.autograd.Function):
         wqkv = _packed_view(wq, wk, wv)
         dwq = dwk = dwv = None
         if need[2] or need[3] or need[4]:
-            h, _, _ = ops.rmsnorm_fwd(x, w_in, eps)  # recomputed
+            h = h_keep if h_keep is not None else ops.rmsnorm_fwd(x, w_in, eps)[0]  # kept, or recomputed
             if wqkv is not None and need[2] and need[3] and need[4]:
                 dwqkv = ops.linear_wgrad(d2, h)
                 dwq, dwk, dwv = dwqkv[:nq], dwqkv[nq:nq + nkv], dwqkv[nq + nkv:]
