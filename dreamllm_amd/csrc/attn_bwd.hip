@@ -342,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq8_kernel(AttnParams P) {
         // ---- fragment stream
         constexpr int NS = 2 * DS;        // steps per segment (= DT)
         constexpr int NSTEP = 6 * NS;
-        constexpr int PRE = 4, RING = PRE + 1;
+        constexpr int PRE = 3, RING = PRE + 1;  // fragments in flight; 2...5 measure the same (+-1 %), 6 is 2 % slower
         u32x4 ring[RING];  // one ring for both fragment kinds: a column fragment = two transpose reads composed into one register quad
         uint32_t raddr[DS];   // row fragments: (row t, chunk ds*4 + g) of the unified image; start at buffer 0, toggled per tile
 #pragma unroll
