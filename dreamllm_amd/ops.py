@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Optional
 
 import torch
@@ -220,11 +221,53 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     sk = _lib.call("dllm_gemm_splitk_hint", M, N, K) if SPLITK else 1
     ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
     cnt = _splitk_counters(a.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-M // 128) * -(-N // 128) <= 16384) else None
+    variant = GEMM_VARIANT
+    if variant == 0 and GEMM_TUNE_GROUP_M and sk == 1 and 2.0 * M * N * K >= _TUNE_MIN_FLOPS:
+        variant = _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha) << 16
     with _GemmTimer(2.0 * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
         check("dllm_gemm_bf16_splitk", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
               ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),
-              sk, _p(ws), _p(cnt), GEMM_VARIANT, _stream())
+              sk, _p(ws), _p(cnt), variant, _stream())
     return out
+
+
+# ---- GROUP_M of the grouped tile order, measured once per (layout, M, N, K) --------------------------------------------------
+# The best GROUP_M is not a function of the layout alone: sustained sweeps over the decoder layer's GEMMs (tools/gemm_sustained.py,
+# profiles/r02_gemm_groupm_sustained.log) put it at 3 for the packed q|k|v and the down projection forward, 8 for the packed gate|up
+# forward, 3-4 for the weight gradients -- 3...5 % apart from the per-layout defaults of the C side, and spiky in between (L2 /
+# Infinity-Cache residency of the panels an XCD's 32 concurrent tiles share).  So the first large call of a shape times the
+# candidates on the real operands (3 launches each after one warm-up, idempotent launches only) and the winner is cached for the
+# process; tile order never changes results.  Skipped under stream capture and for accumulating launches.
+GEMM_TUNE_GROUP_M = os.environ.get("DREAMLLM_GEMM_TUNE", "1") != "0"
+_TUNE_MIN_FLOPS = 5e11
+_TUNE_CANDIDATES = (2, 3, 4, 6, 8)
+_GROUP_M_CACHE = {}
+
+
+def _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha):
+    key = (a.device.index, layout_a, layout_b, M, N, K)
+    gm = _GROUP_M_CACHE.get(key)
+    if gm is not None:
+        return gm
+    if accumulate or torch.cuda.is_current_stream_capturing():
+        return 0  # default of the C side; not cached (a later idempotent call of the shape may still tune)
+    best, best_t = 0, None
+    args = (_p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0), ldr if residual is not None else 0,
+            layout_a, layout_b, EPI[epi], _dt(out), 0, float(alpha), 1, None, None)
+    st = _stream()
+    for cand in _TUNE_CANDIDATES:
+        check("dllm_gemm_bf16_splitk", *args, cand << 16, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            check("dllm_gemm_bf16_splitk", *args, cand << 16, st)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if best_t is None or t < best_t:
+            best, best_t = cand, t
+    _GROUP_M_CACHE[key] = best
+    return best
 
 
 def _as2d(x):

@@ -12,25 +12,30 @@ from dreamllm_amd import ops  # noqa: E402
 
 BF = torch.bfloat16
 gms = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "2,4,8,16").split(",")]
-T, N, K = 32768, 22016, 4096
-x = torch.randn(T, K, device="cuda").to(BF)
-w = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
-dy = torch.randn(T, N, device="cuda").to(BF)
-fns = {"fwd": lambda: ops.linear_fwd(x, w), "dgrad": lambda: ops.linear_dgrad(dy, w), "wgrad": lambda: ops.linear_wgrad(dy, x)}
-flops = 2.0 * T * N * K
-for kind, fn in fns.items():
-    line = f"{kind:6s}"
-    for gm in gms:
-        with ops.gemm_variant(0, gm):
-            fn()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = 0
-            while time.perf_counter() - t0 < 2.5:
-                for _ in range(20):
-                    fn()
+secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.5
+T = 32768
+# (name, N = out features, K = in features) of the decoder layer's linears (packed q|k|v and gate|up) and one lm_head chunk
+shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate|up", 22016, 4096), ("down", 4096, 11008)]
+for name, N, K in shapes:
+    x = torch.randn(T, K, device="cuda").to(BF)
+    w = (torch.randn(N, K, device="cuda") * 0.05).to(BF)
+    dy = torch.randn(T, N, device="cuda").to(BF)
+    fns = {"fwd": lambda: ops.linear_fwd(x, w), "dgrad": lambda: ops.linear_dgrad(dy, w), "wgrad": lambda: ops.linear_wgrad(dy, x)}
+    flops = 2.0 * T * N * K
+    for kind, fn in fns.items():
+        line = f"{name:8s} {kind:6s}"
+        for gm in gms:
+            with ops.gemm_variant(0, gm):
+                fn()
                 torch.cuda.synchronize()
-                n += 20
-            dt = (time.perf_counter() - t0) / n
-        line += f"  gm{gm}: {flops / dt / 1e12:6.0f} TF"
-    print(line, flush=True)
+                t0 = time.perf_counter()
+                n = 0
+                while time.perf_counter() - t0 < secs:
+                    for _ in range(20):
+                        fn()
+                    torch.cuda.synchronize()
+                    n += 20
+                dt = (time.perf_counter() - t0) / n
+            line += f"  gm{gm}: {flops / dt / 1e12:5.0f}"
+        print(line, flush=True)
+    del x, w, dy
