@@ -832,7 +832,7 @@ def gather_rows_unique(x2d, idx):
     return GatherRowsFn.apply(x2d, idx)
 
 
-LM_HEAD_CE_CHUNK_ROWS = 4096  # rows of hidden states per chunk of the fused lm_head + CE (525 MB of fp32 logits at V = 32008)
+LM_HEAD_CE_CHUNK_ROWS = int(os.environ.get("DREAMLLM_CE_CHUNK_ROWS", "4096"))  # rows of hidden states per chunk of the fused lm_head + CE (525 MB of fp32 logits at V = 32008)
 
 
 def _pad_vocab(weight):
