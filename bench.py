@@ -54,16 +54,40 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(seq_len):
+def _median3(fn, reps=3):
+    """median wall time of `reps` runs of fn() (median of >= 3 after one warm-up)."""
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def cpu_baseline(seq_len, budget_s=60.0):
     """Oracle (`oracle/*_ref.py`, kind "port") timed on the host cores (baseline only): (i) one Vicuna-7B decoder
     layer forward+backward at B=1, S=seq_len, fp32, x32 layers + lm_head/CE; (ii) the CLIP-ViT-L/14 encoder forward on one
     image (x K_c = 2, frozen: forward only); (iii) the restated SD-2.1 UNet on one CFG batch (2 x [4,64,64], 64 context tokens):
     its time is the CPU denoise step, and 2 x forward stands for the training pass (forward + input gradient) of each of the
-    K_g = 2 dream images.  Bounded to ~20-30 s of CPU work: every piece is run once after a short warm-up piece."""
+    K_g = 2 dream images.  Every piece: one warm-up, then the MEDIAN of 3 runs (a piece whose warm-up alone shows that three
+    more runs would not fit the budget is timed once and says so)."""
     from oracle import llm_ref, unet_ref
     torch.manual_seed(0)
     H, Fd, nh = 4096, 11008, 32
     S = seq_len
+    t_start = time.perf_counter()
+    reps_used = {}
+
+    def piece(name, fn):
+        t0 = time.perf_counter()
+        fn()                                        # warm-up (thread pool, allocator, lazy inits)
+        w = time.perf_counter() - t0
+        left = budget_s - (time.perf_counter() - t_start)
+        reps = 3 if 3.2 * w < left else 1
+        reps_used[name] = reps
+        return _median3(fn, reps)
+
     sd = {}
     for n, shp in (("self_attn.q_proj.weight", (H, H)), ("self_attn.k_proj.weight", (H, H)), ("self_attn.v_proj.weight", (H, H)),
                    ("self_attn.o_proj.weight", (H, H)), ("mlp.gate_proj.weight", (Fd, H)), ("mlp.up_proj.weight", (Fd, H)),
@@ -76,19 +100,15 @@ def cpu_baseline(seq_len):
     mask = llm_ref.causal_mask_4d(None, 1, S, torch.float32)
     pos = torch.arange(S)[None]
 
-    def layer(x):
+    def layer():
+        x = torch.randn(1, S, H, requires_grad=True)
         llm_ref.decoder_layer(x, sd, "", cfg, cos, sin, pos, mask).square().mean().backward()
 
-    layer(torch.randn(1, S, H, requires_grad=True)[:, :S])  # warm-up (thread pool, allocator)
-    t0 = time.perf_counter()
-    layer(torch.randn(1, S, H, requires_grad=True))
-    t_layer = time.perf_counter() - t0
+    t_layer = piece("layer", layer)
     w = (torch.randn(32008, H) * 0.02).requires_grad_(True)
     h = torch.randn(S, H, requires_grad=True)
     lab = torch.randint(0, 32008, (S,))
-    t0 = time.perf_counter()
-    torch.nn.functional.cross_entropy((h @ w.t()).float(), lab).backward()
-    t_head = time.perf_counter() - t0
+    t_head = piece("head", lambda: torch.nn.functional.cross_entropy((h @ w.t()).float(), lab).backward())
     del sd, w, h, mask
     # (ii) CLIP-ViT-L/14 forward, one image
     t_clip = None
@@ -96,26 +116,24 @@ def cpu_baseline(seq_len):
         from transformers import CLIPVisionConfig, CLIPVisionModel
         clip = CLIPVisionModel(CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24,
                                                 num_attention_heads=16, image_size=224, patch_size=14)).eval()
+        px = torch.randn(1, 3, 224, 224)
         with torch.no_grad():
-            t0 = time.perf_counter()
-            clip(torch.randn(1, 3, 224, 224), output_hidden_states=True)
-            t_clip = time.perf_counter() - t0
+            t_clip = piece("clip", lambda: clip(px, output_hidden_states=True))
         del clip
     except Exception:  # the CLIP share is 0.4 % of the sample's FLOPs: report without it rather than fail
         t_clip = None
     # (iii) restated SD-2.1 UNet, one CFG step (batch 2) at 64x64 latents
     ucfg = dict(unet_ref.SD21_BASE)
     usd = unet_ref.random_state_dict(ucfg, seed=0)
+    xin, tin, cin = torch.randn(2, 4, 64, 64), torch.tensor([500]), torch.randn(2, 64, 1024)
     with torch.no_grad():
-        t0 = time.perf_counter()
-        unet_ref.unet_forward(torch.randn(2, 4, 64, 64), torch.tensor([500]), torch.randn(2, 64, 1024), usd, ucfg)
-        t_unet2 = time.perf_counter() - t0
+        t_unet2 = piece("unet", lambda: unet_ref.unet_forward(xin, tin, cin, usd, ucfg))
     del usd
     K = 2
     t_sample = 32 * t_layer + t_head + K * (t_clip or 0.0) + K * t_unet2  # K_g images x (fwd + dgrad ~ 2 fwd) = K x one batch-2 fwd x 2 / 2
     return dict(value=1.0 / t_sample, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                denoise_steps_per_s=round(1.0 / t_unet2, 4),
-                sample=f"oracle ports (CLIP: installed transformers class), fp32, one piece each: decoder layer fwd+bwd B=1 S={S} ({t_layer:.2f} s, x32) + lm_head/CE "
+                denoise_steps_per_s=round(1.0 / t_unet2, 4), timing="median of 3 after one warm-up per piece", runs_per_piece=reps_used,
+                sample=f"oracle ports (CLIP: installed transformers class), fp32: decoder layer fwd+bwd B=1 S={S} ({t_layer:.2f} s, x32) + lm_head/CE "
                        f"({t_head:.2f} s) + CLIP-L/14 fwd ({'n/a' if t_clip is None else f'{t_clip:.2f} s'}, x{K}) + SD-2.1 UNet CFG "
                        f"step batch 2 ({t_unet2:.2f} s = the CPU denoise step; x{K} stands for fwd+dgrad of {K} dream images); "
                        f"VAE not included; host has {os.cpu_count()} logical cores")
@@ -140,6 +158,19 @@ def main():
     from dreamllm_amd.synthetic import make_interleaved_batch
 
     D.init_distributed("nccl")
+    # N > 1 must be RCCL with exactly N ranks -- fail loudly, never measure a silent single-process or gloo run
+    rccl_ranks = 1
+    if a.gpus > 1:
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_backend() != "nccl" or dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: needs {a.gpus} ranks on backend nccl (= RCCL), found "
+                             f"{'no process group' if not dist.is_initialized() else (dist.get_backend(), dist.get_world_size())}; "
+                             "launch with python -m torch.distributed.run --nproc-per-node N ...")
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)                      # an all-reduce that actually ran on RCCL: every rank contributes 1
+        rccl_ranks = int(ones.item())
+        if rccl_ranks != a.gpus:
+            raise SystemExit(f"RCCL all-reduce saw {rccl_ranks} ranks, expected {a.gpus}")
     tiny = a.model == "tiny"
     if tiny:
         model = build_dreamllm(TINY, device=dev, clip=TINY_CLIP, diffusion=TINY_DIFFUSION, num_dream_queries=8)
@@ -167,23 +198,27 @@ def main():
             if tiny:
                 kw.update(height=128, width=128)
             head.pipeline(generator=torch.Generator().manual_seed(42), **{**kw, "num_inference_steps": 2})  # warm-up + graph capture
-            D.synchronize()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            head.pipeline(generator=torch.Generator().manual_seed(42), **kw)
-            torch.cuda.synchronize()
-            dt = D.max_over_ranks(time.perf_counter() - t0)
+            dts = []
+            for _ in range(3):      # median of 3 full 50-step loops (each 0.3-1.5 s): one loop alone moves +-3 % with the clock
+                D.synchronize()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                head.pipeline(generator=torch.Generator().manual_seed(42), **kw)
+                torch.cuda.synchronize()
+                dts.append(D.max_over_ranks(time.perf_counter() - t0))
+            dt = sorted(dts)[1]
             sps = world * a.denoise_steps / dt
             tf = sps / world * 2 * Bi * FLOPS_UNET_FWD / 1e12
             legs.append(dict(
                 metric="SD-2.1 512px denoise steps/s (50 DDIM eta=0, CFG 7.5, replicas)", value=round(sps, 3), unit="steps/s",
                 batch_images=Bi, unet_batch=2 * Bi, ms_per_step=round(1e3 * dt / a.denoise_steps, 3),
+                loops_timed=3, loop_s=[round(x, 4) for x in dts],
                 roofline=None if tiny else dict(
                     bound="mfma", kernel="SD-2.1 UNet forward (conv + GEMM + attention launches of one step, hipGraph replay)",
                     achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_TFLOPS, 4), traffic=None,
                     note="achieved = algorithmic 2*B_img*0.803 TFLOP per step / measured step time (whole loop body: the launches "
                          "live inside one hipGraph replay, so per-launch HIP events do not apply); kernel-level shares: "
-                         "profiles/r02_denoise_kernel_stats.csv")))
+                         "profiles/r03_denoise_kernel_stats.csv")))
         denoise = dict(legs[0], legs=legs) if legs else None
         if denoise is not None and not tiny:
             denoise["frac_mfma_peak"] = legs[0]["roofline"]["frac"]
@@ -193,11 +228,15 @@ def main():
     if not a.no_train:
         model.train()
         params = [p for p in model.parameters() if p.requires_grad]
+        timeline = None
         if a.sharded_grad and world > 1:
             ddp = model
-            opt = D.ShardedGradAdamW(params, lr=2e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, overlap=True)
+            from dreamllm_amd.modeling_dreamllm import packed_parameter_groups
+            opt = D.ShardedGradAdamW(params, lr=2e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0, overlap=True,
+                                     atomic_groups=packed_parameter_groups(model))
         else:
-            ddp = D.wrap_ddp(model)
+            timeline = D.BucketTimeline() if world > 1 else None   # per-bucket ready / all-reduce-done events -> comm_exposed_ms
+            ddp = D.wrap_ddp(model, timeline=timeline)
             opt = HipAdamW(params, lr=2e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.0, max_grad_norm=1.0)
         if tiny:
             batch = make_interleaved_batch(a.batch, 512, 1, n_dream=8, n_patch=16, seed=1234 + rank, device=dev, image_size=56,
@@ -227,12 +266,15 @@ def main():
         D.synchronize()
         torch.cuda.synchronize()
         ops.GEMM_PROFILE = []
+        if timeline is not None:
+            timeline.reset()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             out = step()
         torch.cuda.synchronize()
         D.synchronize()
         dt = D.max_over_ranks(time.perf_counter() - t0)
+        comm = timeline.summary() if timeline is not None else None
         prof, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
         loss_val = float(out.loss.item())
         gsum = sum(f for _, _, f, _ in prof)
@@ -272,6 +314,7 @@ def main():
                                    for k, v in by_tag.items() if v[1] > 0}),
             e2e_frac_mfma_peak=None if tiny else round(value / world * FLOPS_TRAIN_SAMPLE / (PEAK_BF16_TFLOPS * 1e12), 4),
             peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1),
+            comm=comm,
         )
 
     # ------------------------------------------------------------------ the other BASELINE.json configs (N = 1 only, short)
@@ -315,6 +358,11 @@ def main():
             "roofline": train.get("roofline"),
             "e2e_frac_mfma_peak": train.get("e2e_frac_mfma_peak"),
             "peak_hbm_gb": train.get("peak_hbm_gb"),
+            # ranks an all-reduce on backend nccl (= RCCL) actually summed over; DDP's per-bucket timeline of rank 0 (N > 1):
+            # comm_exposed_ms = last all-reduce done - last bucket ready = communication the backward did not hide
+            "rccl_ranks": rccl_ranks,
+            "comm_exposed_ms": (train.get("comm") or {}).get("comm_exposed_ms"),
+            "comm": train.get("comm"),
             "denoise": denoise,
             "configs": configs,
         }

@@ -59,15 +59,107 @@ def synchronize():
             dist.barrier()
 
 
-def wrap_ddp(model: torch.nn.Module, bucket_cap_mb: int = 512):
+class BucketTimeline:
+    """Per-bucket timeline of DDP's gradient all-reduce, so that the first scaling run on real xGMI is diagnosable: a comm hook
+    (`DDP.register_comm_hook`) that performs the default all-reduce(mean) and records, per bucket, WHEN the bucket became ready
+    (the backward has written its last gradient: an event on the compute stream) and WHEN its all-reduce finished (an event
+    recorded from the future's completion callback, i.e. on the stream that is ordered after the collective).
+
+    `summary()` -> per step (averaged over the recorded steps):
+        comm_exposed_ms   last all-reduce done - last bucket ready: the communication the backward could NOT hide (at least the
+                          last bucket's own all-reduce; everything beyond it is a backlog of earlier buckets)
+        comm_busy_ms      sum over buckets of (done - max(ready, previous bucket done)): time the fabric was reducing
+        backward_span_ms  first bucket ready -> last bucket ready
+        buckets           count, bytes, and the bucket -> first-parameter order of one step (reverse layer order expected)
+    CPU / gloo (the tests): time.perf_counter() instead of events."""
+
+    def __init__(self, process_group=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group)
+        self.records = []       # per bucket launch: dict(index, bytes, ready, done, is_last)
+        self.enabled = True
+        self._cuda = None
+
+    def _now(self, cuda):
+        if cuda:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            return e
+        import time as _t
+        return _t.perf_counter()
+
+    def hook(self, _state, bucket):
+        buf = bucket.buffer()
+        cuda = buf.is_cuda
+        self._cuda = cuda
+        rec = None
+        if self.enabled:
+            rec = dict(index=bucket.index(), bytes=buf.numel() * buf.element_size(), ready=self._now(cuda), done=None,
+                       is_last=bool(bucket.is_last()), first_param_numel=int(bucket.parameters()[0].numel()))
+            self.records.append(rec)
+        fut = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True).get_future()
+        world = self.world
+
+        def _done(f):
+            out = f.value()[0]
+            out.div_(world)                       # mean, as DDP's built-in reducer
+            if rec is not None:
+                rec["done"] = self._now(cuda)
+            return out
+
+        return fut.then(_done)
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        recs = [r for r in self.records if r["done"] is not None]
+        if not recs:
+            return None
+        if self._cuda:
+            torch.cuda.synchronize()
+            ms = lambda a, b: a.elapsed_time(b)
+        else:
+            ms = lambda a, b: (b - a) * 1e3
+        steps, cur = [], []
+        for r in recs:
+            cur.append(r)
+            if r["is_last"]:
+                steps.append(cur)
+                cur = []
+        if not steps:
+            steps = [recs]
+        exposed, busy, span = [], [], []
+        for st in steps:
+            exposed.append(ms(st[-1]["ready"], st[-1]["done"]))
+            span.append(ms(st[0]["ready"], st[-1]["ready"]))
+            b, prev_done = 0.0, None
+            for r in st:
+                start_after_prev = prev_done is not None and ms(r["ready"], prev_done) > 0
+                b += ms(prev_done, r["done"]) if start_after_prev else ms(r["ready"], r["done"])
+                prev_done = r["done"]
+            busy.append(b)
+        avg = lambda v: round(sum(v) / len(v), 3)
+        one = steps[-1]
+        return dict(steps=len(steps), buckets_per_step=len(one), bucket_mb=[round(r["bytes"] / 2**20, 1) for r in one],
+                    bucket_order=[r["index"] for r in one], comm_exposed_ms=avg(exposed), comm_busy_ms=avg(busy),
+                    backward_span_ms=avg(span))
+
+
+def wrap_ddp(model: torch.nn.Module, bucket_cap_mb: int = 512, timeline: BucketTimeline | None = None):
+    """`timeline`: a `BucketTimeline` whose comm hook replaces DDP's built-in all-reduce by the same all-reduce(mean) plus
+    per-bucket ready / done timestamps (bench.py exports its summary as `comm_exposed_ms`)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     kw = {}
     if next(model.parameters()).is_cuda:
         kw = dict(device_ids=[torch.cuda.current_device()], output_device=torch.cuda.current_device())
-    return DDP(model, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, static_graph=True,
-               find_unused_parameters=False, broadcast_buffers=False, **kw)
+    ddp = DDP(model, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True, static_graph=True,
+              find_unused_parameters=False, broadcast_buffers=False, **kw)
+    if timeline is not None:
+        ddp.register_comm_hook(None, timeline.hook)
+    return ddp
 
 
 def shard_for_rank(n_items: int, rank: int | None = None, world: int | None = None):
@@ -123,7 +215,7 @@ class ShardedGradAdamW:
     tests inject a torch restatement (the product path has no CPU fallback)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None, bucket_mb=512,
-                 state_dtype=None, update_fn=None, sumsq_fn=None, process_group=None, overlap=False):
+                 state_dtype=None, update_fn=None, sumsq_fn=None, process_group=None, overlap=False, atomic_groups=None):
         """`overlap=True`: a bucket's reduce-scatter is issued (async, on the communication stream) from a
         post-accumulate-grad hook the moment the LAST gradient of the bucket has been written by the backward -- buckets are
         filled in reverse layer order, so the collectives of the late layers run under the backward of the early ones, as DDP's
@@ -132,7 +224,11 @@ class ShardedGradAdamW:
         `params`: an iterable of parameters, or torch-style param groups `[{"params": [...], "weight_decay": 0.0}, ...]`
         (the reference trainer excludes biases and `ALL_LAYERNORM_LAYERS` weights from decay, omni/train/trainer.py:388-411):
         a bucket never mixes decay values.  Invariant shared with DDP's `static_graph`: every trainable parameter receives
-        a gradient every step (the gradients live in flat buffers, so "no gradient" cannot be told from a zero gradient)."""
+        a gradient every step (the gradients live in flat buffers, so "no gradient" cannot be told from a zero gradient).
+
+        `atomic_groups`: parameter lists that must not be split by a bucket boundary -- the q|k|v and gate|up weights a decoder
+        layer applies as ONE packed GEMM (`modeling_dreamllm.packed_parameter_groups(model)`): a cut between them would silently
+        drop the layer back to one GEMM per projection."""
         self.pg = process_group
         self.world = dist.get_world_size(self.pg) if dist.is_initialized() else 1
         self.rank = dist.get_rank(self.pg) if dist.is_initialized() else 0
@@ -165,10 +261,22 @@ class ShardedGradAdamW:
             raise ValueError("no trainable parameters")
         # buckets in REVERSE registration order: the last layers' gradients are complete first
         cap = bucket_mb * 1024 * 1024
+        gid, gbytes = {}, {}
+        for gi, grp in enumerate(atomic_groups or ()):
+            for q in grp:
+                gid[id(q)] = gi
+            gbytes[gi] = sum(q.numel() * q.element_size() for q in grp)
         self.buckets, self.bucket_wd, cur, cur_bytes, cur_wd = [], [], [], 0, None
+        open_group = None   # atomic group whose first member (in reverse order) is already in `cur`
         for p, wd in reversed(flat):
             nb = p.numel() * p.element_size()
-            if cur and (cur_bytes + nb > cap or p.dtype != cur[0].dtype or p.device != cur[0].device or wd != cur_wd):
+            g = gid.get(id(p))
+            if g is not None and g == open_group:
+                need = 0            # the whole group was accounted for when its first member arrived: never cut inside it
+            else:
+                need = gbytes[g] if g is not None else nb
+                open_group = g
+            if cur and ((need and cur_bytes + need > cap) or p.dtype != cur[0].dtype or p.device != cur[0].device or wd != cur_wd):
                 self.buckets.append(cur)
                 self.bucket_wd.append(cur_wd)
                 cur, cur_bytes = [], 0
@@ -214,6 +322,17 @@ class ShardedGradAdamW:
     def _make_hook(self, bi):
         def hook(_param):
             self._left[bi] -= 1
+            if self._left[bi] < 0 or (self._left[bi] == 0 and self._pending[bi] is not None):
+                # a second backward before step() (gradient accumulation, a skipped step): the reduce-scatter already in flight
+                # saw only the first backward's gradients.  Drop it; step() then reduces the accumulated buffer synchronously.
+                pend, self._pending[bi] = self._pending[bi], None
+                if pend is not None and pend[0] is not None:
+                    pend[0].wait()
+                    if not self.tensor_collectives:
+                        raise RuntimeError("ShardedGradAdamW(overlap=True): a second backward before step() on a backend whose "
+                                           "reduce is in place (gloo all_reduce) cannot be undone; use overlap=False for "
+                                           "gradient accumulation")
+                return
             if self._left[bi] == 0:
                 self._pending[bi] = self._launch_reduce(bi, async_op=True)
         return hook
@@ -321,7 +440,7 @@ def save_dreamllm_full_state_dict(model, output_dir: str, rank: int | None = Non
     rank = get_rank() if rank is None else rank
     inner = model.module if hasattr(model, "module") else model
     state_dict = inner.state_dict()
-    weights = {}
+    prefixes = {}
     for plugin_name, ptype in inner.config.plugins_type.items():
         if ptype == "embedding":
             plugin, prefix = getattr(inner.get_decoder(), plugin_name), f"model.{plugin_name}."
@@ -329,11 +448,16 @@ def save_dreamllm_full_state_dict(model, output_dir: str, rank: int | None = Non
             plugin, prefix = getattr(inner, plugin_name), f"{plugin_name}."
         else:
             continue
-        weights[plugin.save_model_name] = OrderedDict((k[len(prefix):], v) for k, v in state_dict.items() if k.startswith(prefix))
+        prefixes[plugin.save_model_name] = prefix
     if rank == 0:
         _os.makedirs(output_dir, exist_ok=True)
+        # `torch.save` serialises the WHOLE storage behind a view: parameters that live in ShardedGradAdamW's flat 512 MB buckets
+        # (or in a packed q|k|v buffer) would each drag their bucket into the file (a 0.5 MB dream_embedding.bin of 512 MB).
+        # Write compact CPU copies instead.
+        state_dict = OrderedDict((k, v.detach().cpu() if v.is_cuda else v.detach().clone()) for k, v in state_dict.items())
         torch.save(state_dict, _os.path.join(output_dir, "pytorch_model.bin"))
-        for name, sd in weights.items():
+        for name, prefix in prefixes.items():
+            sd = OrderedDict((k[len(prefix):], v) for k, v in state_dict.items() if k.startswith(prefix))
             torch.save(sd, _os.path.join(output_dir, f"{name}.bin"))
     synchronize()
-    return sorted(weights)
+    return sorted(prefixes)

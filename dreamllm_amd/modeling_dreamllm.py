@@ -19,7 +19,8 @@ from __future__ import annotations
 
 import math
 import os
-from dataclasses import dataclass
+from collections import OrderedDict
+from dataclasses import dataclass, fields
 from typing import Any
 
 import torch
@@ -140,6 +141,18 @@ def pack_linear_weights(*linears):
         n = w.shape[0]
         w.data = buf[r:r + n]
         r += n
+
+
+def packed_parameter_groups(model):
+    """The parameter groups every decoder layer of `model` applies as one packed GEMM: [[q, k, v], [gate, up]] per layer -- what
+    `distributed.ShardedGradAdamW(atomic_groups=...)` must keep inside one flat bucket."""
+    out = []
+    for m in model.modules():
+        if isinstance(m, DreamLLMDecoderLayer):
+            a, f = m.self_attn, m.mlp
+            out.append([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight])
+            out.append([f.gate_proj.weight, f.up_proj.weight])
+    return out
 
 
 # 288 GB of HBM per MI355X: the normed inputs of the two GEMM groups and the SwiGLU product (1.26 GB per layer, 40 GB for the 7B
@@ -435,7 +448,7 @@ class DreamLLMDecoderLayer(nn.Module):
         self.mlp = DreamLLMMLP(config)
         self.input_layernorm = DreamLLMRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = DreamLLMRMSNorm(config.hidden_size, eps=config.rms_norm_eps)
-        self._pack_tried = False
+        self._pack_key = None
 
     def pack_weights(self):
         """q/k/v and gate/up weights as row blocks of one buffer each => one GEMM per group (`pack_linear_weights`).  Skipped
@@ -454,9 +467,18 @@ class DreamLLMDecoderLayer(nn.Module):
         if output_attentions:
             raise ValueError("output_attentions is not available on the flash-attention path (modeling_dreamllm.py:934-936)")
         a = self.self_attn
-        if not self._pack_tried and hidden_states.is_cuda and getattr(a.config, "pack_projection_weights", True):
-            self._pack_tried = True  # once: after `.to(device, dtype)` has settled the parameters (0.4 GB of copies per 7B layer)
-            self.pack_weights()
+        if hidden_states.is_cuda and getattr(a.config, "pack_projection_weights", True):
+            # cheap per-forward check (five pointer reads): `.to(dtype/device)`, `.half()` or a re-assigned parameter drop the
+            # packing; re-pack then instead of silently falling back to five GEMMs (0.4 GB of copies per 7B layer, once)
+            key = (a.q_proj.weight.data_ptr(), a.k_proj.weight.data_ptr(), a.v_proj.weight.data_ptr(),
+                   self.mlp.gate_proj.weight.data_ptr(), self.mlp.up_proj.weight.data_ptr())
+            if key != self._pack_key:
+                if not self.pack_weights() and _packed_view(a.q_proj.weight.data, a.k_proj.weight.data, a.v_proj.weight.data) is None:
+                    logger.warning("DreamLLMDecoderLayer: q|k|v / gate|up weights are owned by a flat optimizer buffer that splits "
+                                   "them: running one GEMM per projection (pass `atomic_groups=packed_parameter_groups(model)` "
+                                   "to ShardedGradAdamW)")
+                self._pack_key = (a.q_proj.weight.data_ptr(), a.k_proj.weight.data_ptr(), a.v_proj.weight.data_ptr(),
+                                  self.mlp.gate_proj.weight.data_ptr(), self.mlp.up_proj.weight.data_ptr())
         if past_key_value is None:
             B, S, _ = hidden_states.shape
             cos, sin = a.rotary_emb.tables(S, hidden_states.device)
@@ -528,7 +550,12 @@ class CausalLMOutputWithPast(ModelOutput):
             return None
         object.__setattr__(self, "_logits_thunk", None)
         val = thunk()
-        self.logits = val          # ModelOutput.__setattr__ also registers the key
+        self.logits = val          # ModelOutput.__setattr__ registers the key -- at the END of the ordered dict
+        for f in fields(self):     # restore the dataclass order: logits stays in slot 1, as the reference returns it (:1500-1509)
+            if f.name in ("loss", "logits"):
+                continue
+            if OrderedDict.__contains__(self, f.name):
+                self.move_to_end(f.name)
         return val
 
     def __getattribute__(self, name):
@@ -539,12 +566,41 @@ class CausalLMOutputWithPast(ModelOutput):
             return val
         return super().__getattribute__(name)
 
+    # Every positional / mapping view materialises pending logits first, so tuple-style consumers (`out[1]`, `out.to_tuple()`,
+    # `dict(out)`, HF Trainer.prediction_step's `outputs.items()`) see `logits` in its dataclass position.  Attribute access to
+    # `loss` (all the training loop reads) stays free.
+    def keys(self):
+        self._materialize_logits()
+        return super().keys()
+
+    def values(self):
+        self._materialize_logits()
+        return super().values()
+
+    def items(self):
+        self._materialize_logits()
+        return super().items()
+
+    def __iter__(self):
+        self._materialize_logits()
+        return super().__iter__()
+
+    def __len__(self):
+        self._materialize_logits()
+        return super().__len__()
+
+    def __contains__(self, k):
+        if k == "logits":
+            self._materialize_logits()
+        return super().__contains__(k)
+
     def __getitem__(self, k):
-        if k == "logits" and "logits" not in self.keys():
-            val = self.logits
-            if val is not None:
-                return val
+        self._materialize_logits()
         return super().__getitem__(k)
+
+    def to_tuple(self):
+        self._materialize_logits()
+        return super().to_tuple()
 
 
 class DreamLLMPreTrainedModel(PreTrainedModel, FSDPMixin):

@@ -222,8 +222,11 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
     cnt = _splitk_counters(a.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-M // 128) * -(-N // 128) <= 16384) else None
     variant = GEMM_VARIANT
-    if variant == 0 and GEMM_TUNE_GROUP_M and sk == 1 and 2.0 * M * N * K >= _TUNE_MIN_FLOPS:
-        variant = _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha) << 16
+    if variant == 0 and sk == 1:
+        gm = _GROUP_M_TABLE.get((layout_a, layout_b, M, N, K), 0)
+        if gm == 0 and GEMM_TUNE_GROUP_M and 2.0 * M * N * K >= _TUNE_MIN_FLOPS:   # opt-in tool, off in the product path
+            gm = _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha)
+        variant = gm << 16
     with _GemmTimer(2.0 * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
         check("dllm_gemm_bf16_splitk", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
               ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),
@@ -231,17 +234,33 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     return out
 
 
-# ---- GROUP_M of the grouped tile order, measured once per (layout, M, N, K) --------------------------------------------------
+# ---- GROUP_M of the grouped tile order: a table keyed on (layout, M, N, K) --------------------------------------------------
 # The best GROUP_M is not a function of the layout alone: sustained sweeps over the decoder layer's GEMMs (tools/gemm_sustained.py,
 # profiles/r02_gemm_groupm_sustained.log) put it at 3 for the packed q|k|v and the down projection forward, 8 for the packed gate|up
-# forward, 3-4 for the weight gradients -- 3...5 % apart from the per-layout defaults of the C side, and spiky in between (L2 /
-# Infinity-Cache residency of the panels an XCD's 32 concurrent tiles share).  So the first large call of a shape times the
-# candidates on the real operands (3 launches each after one warm-up, idempotent launches only) and the winner is cached for the
-# process; tile order never changes results.  Skipped under stream capture and for accumulating launches.
-GEMM_TUNE_GROUP_M = os.environ.get("DREAMLLM_GEMM_TUNE", "1") != "0"
+# forward, 4 for the weight gradients -- 2...5 % apart from the per-layout defaults of the C side, and spiky in between (L2 /
+# Infinity-Cache residency of the panels an XCD's 32 concurrent tiles share).  Round 2 timed the candidates inside the operator on
+# first use; that made the kernel choice of a process depend on a noisy 3-launch measurement (ranks of one DDP job could disagree,
+# the first step contained host syncs, and the driver's config-5 leg ran 17 % below the builder's).  Round 3: the choice is a
+# STATIC table measured offline (gemm_group_m.json beside this file, regenerated by `tools/gemm_sustained.py --write-table`);
+# shapes that are not in it take the C side's per-layout default.  `DREAMLLM_GEMM_TUNE=1` keeps the in-process timing as a tool.
+GEMM_TUNE_GROUP_M = os.environ.get("DREAMLLM_GEMM_TUNE", "0") == "1"
 _TUNE_MIN_FLOPS = 5e11
 _TUNE_CANDIDATES = (2, 3, 4, 6, 8)
 _GROUP_M_CACHE = {}
+
+
+def _load_group_m_table():
+    import json
+    fn = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_group_m.json")
+    try:
+        with open(fn) as f:
+            raw = json.load(f)
+    except (OSError, ValueError):
+        return {}
+    return {tuple(int(v) for v in k.split(",")): int(gm) for k, gm in raw.get("table", {}).items()}
+
+
+_GROUP_M_TABLE = _load_group_m_table()  # (layout_a, layout_b, M, N, K) -> GROUP_M
 
 
 def _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha):
@@ -861,12 +880,14 @@ class LMHeadCEFn(torch.autograd.Function):
     Same arithmetic as the unfused form (same GEMM kernel, same CE kernel, fp32 accumulation of dW across chunks)."""
 
     @staticmethod
-    def forward(ctx, hidden, weight, labels):
+    def forward(ctx, hidden, weight, labels, with_grads=True):
         R, d = hidden.shape
         V = weight.shape[0]
         wp = _pad_vocab(weight)
         Vp = wp.shape[0]
-        need_dh, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        # `needs_input_grad` is True under torch.no_grad() as well (it reflects requires_grad of the inputs); `lm_head_ce` passes
+        # `with_grads=False` there so that evaluation with labels does not pay for the dgrad / wgrad GEMMs and the fp32 dW buffer
+        need_dh, need_dw = (ctx.needs_input_grad[0] and with_grads), (ctx.needs_input_grad[1] and with_grads)
         nvalid = (labels != -100).sum()
         denom = torch.clamp(nvalid, min=1).to(torch.float32)
         gscale = (1.0 / denom).reshape(1).contiguous()
@@ -898,12 +919,14 @@ class LMHeadCEFn(torch.autograd.Function):
     def backward(ctx, dloss):
         dh, dw = ctx.saved_tensors
         g = dloss.to(torch.float32)
-        # dloss is a scalar (1 / loss_scale, times the lm weight): one multiply per gradient element, in place
+        # dloss is a scalar (1 / loss_scale, times the lm weight): one multiply per gradient element by the fp32 scalar (a value
+        # such as 1/3 from gradient accumulation is not rounded to bf16 first), OUT of place so that a second backward
+        # (retain_graph) scales the saved gradients once, not twice
         if dh is not None:
-            dh = dh.mul_(g.to(dh.dtype))
+            dh = dh.to(torch.float32).mul_(g).to(dh.dtype)   # (bf16 tensor * 0-dim fp32 tensor would round g to bf16 first)
         if dw is not None:
-            dw = dw.mul_(g.to(dw.dtype))
-        return dh, dw, None
+            dw = dw.to(torch.float32).mul_(g).to(dw.dtype)
+        return dh, dw, None, None
 
 
 class LMHeadCELogitsFn(torch.autograd.Function):
@@ -945,7 +968,7 @@ def lm_head_ce(hidden2d, weight, labels1d, return_logits=False):
     """-> loss (fused, no [T,V] tensor) or (loss, fp32 logits) with `return_logits=True` (unfused)."""
     if return_logits:
         return LMHeadCELogitsFn.apply(hidden2d, weight, labels1d)
-    return LMHeadCEFn.apply(hidden2d, weight, labels1d)
+    return LMHeadCEFn.apply(hidden2d, weight, labels1d, torch.is_grad_enabled())
 
 
 # --------------------------------------------------------------------------------------------- UNet operators (NHWC)

@@ -25,10 +25,10 @@ def rmsnorm(x, weight, eps):
     return weight * h.to(dt)
 
 
-def rope_tables(dim, max_pos, base=10000.0, dtype=torch.float32):
+def rope_tables(dim, max_pos, base=10000.0, dtype=torch.float32, device=None):
     """RotaryEmbedding.__init__/_set_cos_sin_cache, modeling_dreamllm.py:97-119 -> cos, sin [max_pos, dim]."""
-    inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
-    t = torch.arange(max_pos, dtype=inv_freq.dtype)
+    inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2, device=device).float() / dim))
+    t = torch.arange(max_pos, dtype=inv_freq.dtype, device=device)
     freqs = torch.einsum("i,j->ij", t, inv_freq)
     emb = torch.cat((freqs, freqs), dim=-1)
     return emb.cos().to(dtype), emb.sin().to(dtype)
@@ -48,10 +48,10 @@ def apply_rope(q, k, cos, sin, position_ids):
     return (q * cos) + (rotate_half(q) * sin), (k * cos) + (rotate_half(k) * sin)
 
 
-def causal_mask_4d(attention_mask, B, S, dtype):
+def causal_mask_4d(attention_mask, B, S, dtype, device=None):
     """HF _prepare_4d_causal_attention_mask as used at modeling_dreamllm.py:965-967 (no KV cache): additive mask."""
     minv = torch.finfo(dtype).min
-    m = torch.full((S, S), minv, dtype=dtype)
+    m = torch.full((S, S), minv, dtype=dtype, device=device)
     m = torch.triu(m, diagonal=1)[None, None].expand(B, 1, S, S).clone()
     if attention_mask is not None:
         pad = (attention_mask[:, None, None, :] == 0)
@@ -102,9 +102,10 @@ def model_forward(inputs_embeds, sd, cfg, attention_mask=None, prefix="model."):
     """DreamLLMModel._forward, modeling_dreamllm.py:846-1043 (eager 4-D mask path, no cache) -> last_hidden_state."""
     B, S, H = inputs_embeds.shape
     hd = H // cfg["num_attention_heads"]
-    cos, sin = rope_tables(hd, max(cfg["max_position_embeddings"], S), cfg.get("rope_theta", 10000.0))
-    position_ids = torch.arange(S)[None]
-    mask4d = causal_mask_4d(attention_mask, B, S, inputs_embeds.dtype)
+    dev = inputs_embeds.device  # the oracle also runs in fp32 ON the GPU for the full-size checks (tests/test_fullsize_models_gpu.py)
+    cos, sin = rope_tables(hd, max(cfg["max_position_embeddings"], S), cfg.get("rope_theta", 10000.0), device=dev)
+    position_ids = torch.arange(S, device=dev)[None]
+    mask4d = causal_mask_4d(attention_mask, B, S, inputs_embeds.dtype, device=dev)
     x = inputs_embeds
     for i in range(cfg["num_hidden_layers"]):
         x = decoder_layer(x, sd, f"{prefix}layers.{i}.", cfg, cos, sin, position_ids, mask4d)

@@ -248,18 +248,18 @@ def param_shapes(cfg):
     return sh
 
 
-def random_state_dict(cfg, seed=0, dtype=torch.float32):
+def random_state_dict(cfg, seed=0, dtype=torch.float32, device="cpu"):
     """Default-PyTorch-like init (uniform +-1/sqrt(fan_in)); norm weights around 1."""
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator(device=device).manual_seed(seed)  # device="cuda": the full-size tests draw 0.9-2.6 G weights on the GPU
     sd = {}
     for k, s in param_shapes(cfg).items():
         if ".norm" in k or k.startswith("conv_norm_out"):
-            t = (1.0 + 0.1 * torch.randn(s, generator=g)) if k.endswith("weight") else 0.1 * torch.randn(s, generator=g)
+            t = (1.0 + 0.1 * torch.randn(s, generator=g, device=device)) if k.endswith("weight") else 0.1 * torch.randn(s, generator=g, device=device)
         elif k.endswith(".weight"):
             fan_in = math.prod(s[1:])
-            t = (torch.rand(s, generator=g) * 2 - 1) / math.sqrt(fan_in)
+            t = (torch.rand(s, generator=g, device=device) * 2 - 1) / math.sqrt(fan_in)
         else:
-            t = (torch.rand(s, generator=g) * 2 - 1) * 0.05
+            t = (torch.rand(s, generator=g, device=device) * 2 - 1) * 0.05
         sd[k] = t.to(dtype)
     return sd
 

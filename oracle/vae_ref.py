@@ -133,16 +133,16 @@ def param_shapes(cfg):
     return sh
 
 
-def random_state_dict(cfg, seed=0, dtype=torch.float32):
+def random_state_dict(cfg, seed=0, dtype=torch.float32, device="cpu"):
     """Seeded default-PyTorch-like init (uniform +-1/sqrt(fan_in)), norm weights around 1 -- reproducible on any host."""
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator(device=device).manual_seed(seed)  # device="cuda": the full-size tests draw 0.9-2.6 G weights on the GPU
     sd = {}
     for k, s in param_shapes(cfg).items():
         if "norm" in k:
-            t = (1.0 + 0.1 * torch.randn(s, generator=g)) if k.endswith("weight") else 0.1 * torch.randn(s, generator=g)
+            t = (1.0 + 0.1 * torch.randn(s, generator=g, device=device)) if k.endswith("weight") else 0.1 * torch.randn(s, generator=g, device=device)
         elif k.endswith(".weight"):
-            t = (torch.rand(s, generator=g) * 2 - 1) / math.sqrt(math.prod(s[1:]))
+            t = (torch.rand(s, generator=g, device=device) * 2 - 1) / math.sqrt(math.prod(s[1:]))
         else:
-            t = (torch.rand(s, generator=g) * 2 - 1) * 0.05
+            t = (torch.rand(s, generator=g, device=device) * 2 - 1) * 0.05
         sd[k] = t.to(dtype)
     return sd

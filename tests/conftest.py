@@ -48,22 +48,29 @@ def rel_l2(a, b):
 _PARITY_LOG = []
 
 
+# Round 3: tightened from 1.5 * err_ref + 2e-3 (which left ~50 % slack and an additive term twice the 1e-3 north_star states).
+# err_ours <= 1.15 * err_ref + 5e-4: a bf16 implementation may be at most 15 % worse than the reference run in bf16, plus half of
+# north_star's 1e-3 for the cases where err_ref itself is ~0 (single-rounding outputs).  Every check of round 2's report passes
+# it (profiles/r02_parity_report.json); a regression of the size the old bound would have hidden now fails.
+SLACK, FLOOR = 1.15, 5e-4
+
+
 def bound(err_ref):
-    return 1.5 * err_ref + 2e-3
+    return SLACK * err_ref + FLOOR
 
 
 def check_tensor(name, ours, ref, err_ref):
-    """assert rel-L2(ours, ref) <= 1.5 * err_ref + 2e-3 and log the measured pair (gpurun_out/parity_report.json)."""
+    """assert rel-L2(ours, ref) <= 1.15 * err_ref + 5e-4 and log the measured pair (gpurun_out/parity_report.json)."""
     e = rel_l2(ours, ref)
     _PARITY_LOG.append(dict(name=name, err=e, err_ref=err_ref, bound=bound(err_ref)))
-    assert e <= bound(err_ref), f"{name}: rel-L2 {e:.3e} > 1.5 * err_ref({err_ref:.3e}) + 2e-3"
+    assert e <= bound(err_ref), f"{name}: rel-L2 {e:.3e} > {SLACK} * err_ref({err_ref:.3e}) + {FLOOR}"
     return e
 
 
 def check_scalar(name, ours, ref, ref_bf16_abs_err=0.0, rtol=1e-3):
-    """fp32 scalar (a loss): |ours - ref| <= 1.5 * |reference_in_bf16 - ref| + 1e-3 * |ref|."""
+    """fp32 scalar (a loss): |ours - ref| <= 1.15 * |reference_in_bf16 - ref| + 1e-3 * |ref| (1e-3: north_star's bound)."""
     ours, ref = float(ours), float(ref)
-    lim = 1.5 * float(ref_bf16_abs_err) + rtol * abs(ref)
+    lim = SLACK * float(ref_bf16_abs_err) + rtol * abs(ref)
     _PARITY_LOG.append(dict(name=name, err=abs(ours - ref) / max(abs(ref), 1e-30), err_ref=float(ref_bf16_abs_err) / max(abs(ref), 1e-30),
                             bound=lim / max(abs(ref), 1e-30), scalar=True))
     assert abs(ours - ref) <= lim, f"{name}: |{ours:.6f} - {ref:.6f}| = {abs(ours - ref):.3e} > {lim:.3e}"

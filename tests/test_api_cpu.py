@@ -256,3 +256,35 @@ def test_data_collator_matches_reference_padding_and_model_slot_order():
         e["add_time_ids"] = torch.ones(1, 6) if e["images_dm"] is not None else None
     b3 = DataCollatorForDreamLLMSDXLDataset(tok, dream_start_id=DS, image_start_id=IS, n_dream=4, n_patch=6)(exs)
     assert b3["add_time_ids"].shape == (2, 6)
+
+
+def test_lazy_logits_keep_the_model_output_contract():
+    """with the fused lm_head + CE path `logits` is lazy, but every positional / mapping view must still show it in
+    slot 1 as the reference returns it (modeling_dreamllm.py:1500-1509): keys / items / to_tuple / out[1] / dict(out) /
+    HF Trainer.prediction_step's `outputs.items()`.  Reading only `.loss` never materialises them."""
+    from dreamllm_amd.modeling_dreamllm import CausalLMOutputWithPast
+    calls = []
+
+    def thunk():
+        calls.append(1)
+        return torch.full((2, 3), 7.0)
+
+    def make():
+        return CausalLMOutputWithPast(loss=torch.tensor(1.0), hidden_states=(torch.zeros(1),),
+                                      additional_log_info={"lm_loss": 1.0}).set_lazy_logits(thunk)
+
+    o = make()
+    assert float(o.loss) == 1.0 and o.additional_log_info["lm_loss"] == 1.0 and not calls
+    assert list(o.keys()) == ["loss", "logits", "hidden_states", "additional_log_info"] and len(calls) == 1
+    o = make()
+    assert o[1].shape == (2, 3) and float(o[1][0, 0]) == 7.0 and o[0] is o.loss
+    o = make()
+    assert [k for k, _ in o.items()] == ["loss", "logits", "hidden_states", "additional_log_info"] and len(o.to_tuple()) == 4
+    o = make()
+    assert "logits" in o and o["logits"].shape == (2, 3) and len(o) == 4
+    o = make()
+    assert list(dict(o)) == ["loss", "logits", "hidden_states", "additional_log_info"]
+    n = len(calls)
+    assert o.logits is o["logits"] and len(calls) == n      # materialised once
+    eager = CausalLMOutputWithPast(loss=torch.tensor(1.0), logits=torch.zeros(1), past_key_values=((1,),))
+    assert list(eager.keys()) == ["loss", "logits", "past_key_values"]

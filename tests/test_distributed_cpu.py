@@ -238,3 +238,50 @@ def test_decay_param_groups_and_plugin_aware_save(tmp_path):
     plug = torch.load(tmp_path / "dream_embedding.bin")
     assert "model.dream_embedding.dream_queries" in full and list(plug) == ["dream_queries"]
     assert torch.equal(plug["dream_queries"], lm.model.dream_embedding.dream_queries.data)
+
+
+def test_full_state_save_is_compact_for_flat_owned_parameters(tmp_path):
+    """plugin tensors that are views into ShardedGradAdamW's flat bucket buffers must be saved as compact copies --
+    `torch.save` of a view serialises the whole underlying storage (a 2 KB dream_embedding.bin would carry the bucket)."""
+    from dreamllm_amd import distributed as D
+    from dreamllm_amd.configuration_dreamllm import DreamLLMConfig
+    from dreamllm_amd.modeling_dreamllm import DreamLLMForCausalMLM
+    from dreamllm_amd.modeling_plugins import DreamEmbedding
+    cfg = DreamLLMConfig(vocab_size=64, hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+                         max_position_embeddings=32)
+    lm = DreamLLMForCausalMLM(cfg)
+    lm.model.dream_embedding = DreamEmbedding(num_dream_queries=4, embed_hidden_size=128)
+    lm.config.plugins_type["dream_embedding"] = "embedding"
+    D.ShardedGradAdamW(lm.parameters(), update_fn=lambda *a: None, sumsq_fn=lambda g: g.float().pow(2).sum())
+    dq = lm.model.dream_embedding.dream_queries
+    assert dq.untyped_storage().nbytes() > 100 * dq.numel() * dq.element_size()   # it IS a view of a big flat buffer now
+    D.save_dreamllm_full_state_dict(lm, str(tmp_path), rank=0)
+    assert os.path.getsize(tmp_path / "dream_embedding.bin") < 4 * dq.numel() * dq.element_size() + 4096
+    n_bytes = sum(p.numel() * p.element_size() for p in lm.state_dict().values())
+    assert os.path.getsize(tmp_path / "pytorch_model.bin") < 1.1 * n_bytes + 65536
+    assert torch.equal(torch.load(tmp_path / "dream_embedding.bin")["dream_queries"], dq.data)
+
+
+def test_sharded_grad_buckets_keep_atomic_groups_together():
+    """a bucket cut must not split q|k|v / gate|up (they are applied as ONE packed GEMM).  With a bucket size that
+    would otherwise cut inside the groups, every group still lands in one bucket, adjacent and in registration order."""
+    from dreamllm_amd import distributed as D
+    from dreamllm_amd.configuration_dreamllm import DreamLLMConfig
+    from dreamllm_amd.modeling_dreamllm import DreamLLMForCausalMLM, _packed_view, packed_parameter_groups
+    cfg = DreamLLMConfig(vocab_size=64, hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2,
+                         max_position_embeddings=32)
+    lm = DreamLLMForCausalMLM(cfg)
+    groups = packed_parameter_groups(lm)
+    assert len(groups) == 6 and [len(g) for g in groups] == [3, 2] * 3
+    kw = dict(update_fn=lambda *a: None, sumsq_fn=lambda g: g.float().pow(2).sum())
+    # 128x128 fp32 = 64 KiB per projection: 0.15 MiB buckets cut after every 2nd projection without the hint
+    opt = D.ShardedGradAdamW(lm.parameters(), bucket_mb=0.15, atomic_groups=groups, **kw)
+    where = {id(p): bi for bi, b in enumerate(opt.buckets) for p in b}
+    for g in groups:
+        assert len({where[id(p)] for p in g}) == 1
+        assert _packed_view(*[p.data for p in g]) is not None      # adjacent row blocks of the flat buffer, in order
+    assert len(opt.buckets) > 6
+    lm2 = DreamLLMForCausalMLM(cfg)
+    opt2 = D.ShardedGradAdamW(lm2.parameters(), bucket_mb=0.15, **kw)
+    where2 = {id(p): bi for bi, b in enumerate(opt2.buckets) for p in b}
+    assert any(len({where2[id(p)] for p in g}) > 1 for g in packed_parameter_groups(lm2))   # the hint is what keeps them whole

@@ -6,17 +6,17 @@ bf16 implementation -- including the reference's own.  Every check therefore mea
     err_ours = ||ours - fp32_reference|| / ||fp32_reference||
 next to the yard-stick
     err_ref  = ||reference_run_in_bf16 - fp32_reference|| / ||fp32_reference||   (oracle evaluated in bf16 on CPU)
-and requires  err_ours <= 1.5 * err_ref + 2e-3 (conftest.check_tensor).  fp32 scalars (loss values) are held to
-|ours - fp32| <= 1.5 * |reference_in_bf16 - fp32| + 1e-3 * |fp32| (conftest.check_scalar): 1e-3 relative, the bound
+and requires  err_ours <= 1.15 * err_ref + 5e-4 (conftest.check_tensor; round 2: 1.5 / 2e-3).  fp32 scalars (loss values) are held to
+|ours - fp32| <= 1.15 * |reference_in_bf16 - fp32| + 1e-3 * |fp32| (conftest.check_scalar): 1e-3 relative, the bound
 north_star states, plus the same yard-stick allowance.  err_ref comes from EXECUTING the reference in bf16
 (tests/golden/err_ref.pt, oracle/make_golden_errref.py).  Every measured (err, err_ref) pair of a run is written to
-gpurun_out/parity_report.json; the round's copy is profiles/r02_parity_report.json.
+gpurun_out/parity_report.json; the round's copy is profiles/r03_parity_report.json.
 """
 import pytest
 import torch
 import torch.nn as nn
 
-from conftest import check_scalar, check_tensor, rel_l2
+from conftest import bound as _bound, check_scalar, check_tensor, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -29,10 +29,6 @@ def _cfg(cd, **kw):
                           num_hidden_layers=cd["num_hidden_layers"], num_attention_heads=cd["num_attention_heads"],
                           num_key_value_heads=cd["num_key_value_heads"], rms_norm_eps=cd["rms_norm_eps"],
                           max_position_embeddings=cd["max_position_embeddings"], **kw)
-
-
-def _bound(err_ref):
-    return 1.5 * err_ref + 2e-3
 
 
 def _bf16_sd(sd):

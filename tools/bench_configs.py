@@ -56,7 +56,7 @@ def config2(out, a, model=None, sink=None):
     ids, img, mask = b["input_ids"], b["images"], b["attention_mask"]
     with torch.no_grad():
         t = timed(lambda: model(input_ids=ids, images=img, attention_mask=mask, image_index=b["image_index"], use_cache=True,
-                                return_dict=True), a.iters, 1)
+                                return_dict=True), a.iters, a.warmup)
     ntok = ids.numel()
     flops = 13.75e9 * ntok + 0.162e12 * img.shape[0]
     emit(out, sink, config=2, metric="image-comprehension prefill tokens/s", value=round(ntok / t, 1), unit="tokens/s",
@@ -132,7 +132,7 @@ def config5(out, a, sink=None):
         opt.step()
         opt.zero_grad(set_to_none=True)
 
-    t = timed(step, a.iters, 1)
+    t = timed(step, a.iters, a.warmup)
     lat = a.sdxl_px // 8
     unet_fwd = 6.89e12 * (lat / 128.0) ** 2  # SDXL UNet fwd @128x128, 196 ctx tokens
     flops = B * (2 * unet_fwd + 2 * 13.75e9 * S)
@@ -153,7 +153,7 @@ def config5(out, a, sink=None):
         head.pipeline(height=a.sdxl_px, width=a.sdxl_px, num_inference_steps=steps, guidance_scale=7.5, latents=lat0.clone(),
                       prompt_embeds=pe, negative_prompt_embeds=ne, output_type="latent", scheduler=sched)
 
-    t = timed(run, 1, 1)
+    t = timed(run, 2, 1)
     emit(out, sink, config=5, metric="SDXL denoise steps/s (DDIM eta=0, CFG 7.5, B_img=1)", value=round(steps / t, 2), unit="steps/s",
          image_px=a.sdxl_px, ms_per_step=round(t / steps * 1e3, 2), frac_mfma_peak=round(2 * unet_fwd * steps / t / 1e12 / PEAK_TF, 4),
          dtype="bf16", data="synthetic")
@@ -163,7 +163,8 @@ def _parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="2,3,5")
     ap.add_argument("--out", default="")
-    ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=5, help="timed iterations per leg (round 2: 3, after ONE warm-up: not reproducible)")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--prompt-len", type=int, default=448)
     ap.add_argument("--prefill-batch", type=int, default=8)
     ap.add_argument("--decode-tokens", type=int, default=64)
