@@ -95,7 +95,7 @@ class BucketTimeline:
         rec = None
         if self.enabled:
             rec = dict(index=bucket.index(), bytes=buf.numel() * buf.element_size(), ready=self._now(cuda), done=None,
-                       is_last=bool(bucket.is_last()), first_param_numel=int(bucket.parameters()[0].numel()))
+                       is_last=bool(bucket.is_last()), param_ptrs=[int(q.data_ptr()) for q in bucket.parameters()])
             self.records.append(rec)
         fut = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True).get_future()
         world = self.world
@@ -142,7 +142,8 @@ class BucketTimeline:
         avg = lambda v: round(sum(v) / len(v), 3)
         one = steps[-1]
         return dict(steps=len(steps), buckets_per_step=len(one), bucket_mb=[round(r["bytes"] / 2**20, 1) for r in one],
-                    bucket_order=[r["index"] for r in one], comm_exposed_ms=avg(exposed), comm_busy_ms=avg(busy),
+                    bucket_order=[r["index"] for r in one], bucket_param_ptrs=[r["param_ptrs"] for r in one],
+                    comm_exposed_ms=avg(exposed), comm_busy_ms=avg(busy),
                     backward_span_ms=avg(span))
 
 

@@ -43,7 +43,7 @@ def make_interleaved_batch(batch_size=16, seq_len=2048, images_per_sample=2, n_d
         ids[b, :L] = torch.tensor(row)
         mask[b, :L] = 1
     labels = ids.clone()
-    for t in ("<im_patch>", "<im_end>", "<dream_end>"):
+    for t in ("<im_patch>", "<im_start>", "<im_end>", "<dream_end>"):   # builder_dreamllm.py:285-288: only <dream_start> is learned
         labels[ids == add[t]] = -100
     labels[mask == 0] = -100
     dpos, ipos = torch.tensor(dream_pos), torch.tensor(image_pos)

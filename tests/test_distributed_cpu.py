@@ -285,3 +285,96 @@ def test_sharded_grad_buckets_keep_atomic_groups_together():
     opt2 = D.ShardedGradAdamW(lm2.parameters(), bucket_mb=0.15, **kw)
     where2 = {id(p): bi for bi, b in enumerate(opt2.buckets) for p in b}
     assert any(len({where2[id(p)] for p in g}) > 1 for g in packed_parameter_groups(lm2))   # the hint is what keeps them whole
+
+
+class _WholeLayerFn(torch.autograd.Function):
+    """Stand-in with the autograd SHAPE of `modeling_dreamllm._DecoderLayerFn` (which needs the GPU): ONE Function per layer that
+    takes every weight of the layer as an input and returns all of their gradients at once from a hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, g):
+        h = torch.tanh(x @ w1.t())
+        ctx.save_for_backward(x, w1, w2, g, h)
+        return x + (h @ w2.t()) * g
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, g, h = ctx.saved_tensors
+        u = h @ w2.t()
+        dg = (dy * u).sum(0)
+        du = dy * g
+        dw2 = du.t() @ h
+        dh = (du @ w2) * (1 - h * h)
+        return dy + dh @ w1, dh.t() @ x, dw2, dg
+
+
+class _Layer(torch.nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.w1 = torch.nn.Parameter(torch.randn(2 * d, d) * 0.1)
+        self.w2 = torch.nn.Parameter(torch.randn(d, 2 * d) * 0.1)
+        self.g = torch.nn.Parameter(torch.ones(d))
+
+    def forward(self, x):
+        return _WholeLayerFn.apply(x, self.w1, self.w2, self.g)
+
+
+def _timeline_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dreamllm_amd import distributed as D
+    D.init_distributed("gloo")
+    torch.manual_seed(0)
+    d, L = 128, 4
+    model = torch.nn.Sequential(*[_Layer(d) for _ in range(L)])   # 2 * 2d*d * 4 B = 256 KiB per layer
+    ref = [p.detach().clone() for p in model.parameters()]
+    tl = D.BucketTimeline()
+    ddp = D.wrap_ddp(model, bucket_cap_mb=0.3, timeline=tl)         # ~one layer per bucket
+    torch.manual_seed(10 + rank)
+    x = torch.randn(8, d)
+    for it in range(3):                                             # static_graph: buckets are rebuilt after iteration 1
+        if it == 2:
+            tl.reset()
+        ddp.zero_grad()
+        ddp(x).square().mean().backward()
+    s = tl.summary()
+    ptr2layer = {int(p.data_ptr()): int(n.split(".")[0]) for n, p in model.named_parameters()}
+    layers_per_bucket = [sorted({ptr2layer[pp] for pp in ptrs}) for ptrs in s["bucket_param_ptrs"]]
+    g = torch.cat([p.grad.flatten() for p in model.parameters()])
+    # single-process reference of the averaged gradient
+    xs = []
+    for r in range(world):
+        torch.manual_seed(10 + r)
+        xs.append(torch.randn(8, d))
+    m2 = torch.nn.Sequential(*[_Layer(d) for _ in range(L)])
+    for p, v in zip(m2.parameters(), ref):
+        p.data.copy_(v)
+    for xr in xs:
+        (m2(xr).square().mean() / world).backward()
+    g2 = torch.cat([p.grad.flatten() for p in m2.parameters()])
+    q.put((rank, s["bucket_order"], layers_per_bucket, s["comm_exposed_ms"], s["comm_busy_ms"], s["steps"],
+           float((g - g2).abs().max()), float(g2.abs().max())))
+    torch.distributed.destroy_process_group()
+
+
+def test_ddp_bucket_timeline_and_reverse_layer_bucket_order():
+    """(i) a whole-layer autograd Function (the shape of `_DecoderLayerFn`) fires DDP's bucket hooks under
+    `static_graph` in REVERSE layer order -- the last layer's bucket is ready first, so its all-reduce runs under the backward of
+    the earlier layers; (ii) `BucketTimeline` (the comm hook bench.py installs for N > 1) reports every bucket of a step with
+    ready / done stamps, performs the same all-reduce(mean) as DDP's built-in reducer, and yields `comm_exposed_ms`."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timeline_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    for rank, order, layers, exposed, busy, steps, err, scale in res:
+        assert steps == 1 and order == list(range(len(order))) and len(order) >= 3
+        firsts = [l[-1] for l in layers]
+        assert firsts == sorted(firsts, reverse=True), layers          # bucket 0 holds the LAST layer, ... (reverse layer order)
+        assert layers[0][-1] == 3 and layers[-1][0] == 0
+        assert exposed >= 0.0 and busy >= exposed * 0.999
+        assert err <= 1e-6 * max(scale, 1.0)                            # the hook's all-reduce(mean) == DDP's averaged gradient
