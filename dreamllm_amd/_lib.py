@@ -25,6 +25,7 @@ SIGNATURES = {
     "dllm_layernorm_bwd": [c_void_p] * 10 + [c_int, c_i64, c_int, c_void_p],
     "dllm_gemm_bf16": [c_void_p] * 5 + [c_i64] * 7 + [c_int] * 5 + [c_float, c_void_p],
     "dllm_gemm_splitk_hint": [c_i64, c_i64, c_i64],
+    "dllm_gemm_streamk_hint": [c_i64, c_i64, c_i64, c_int, c_int],
     "dllm_gemm_bf16_splitk": [c_void_p] * 5 + [c_i64] * 7 + [c_int] * 5 + [c_float, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "dllm_conv2d_nhwc_bf16_splitk": [c_void_p] * 6 + [c_int] * 15 + [c_int, c_void_p, c_void_p, c_int, c_void_p],
     "dllm_conv2d_nhwc_bf16": [c_void_p] * 6 + [c_int] * 15 + [c_void_p],
@@ -61,6 +62,7 @@ SIGNATURES = {
 
 # functions whose return type is not int
 RESTYPES = {"dllm_groupnorm_ws_floats": (c_i64, [c_int, c_int, c_int]),
+            "dllm_gemm_streamk_ws_bytes": (c_i64, []),
             "dllm_attn_decode_ws_floats": (c_i64, [c_int, c_int, c_int, c_int])}
 
 _lib = None

@@ -86,6 +86,9 @@ struct GemmParams {
     int dbg_noload;  // benchmark-only: skip the K-loop prefetches (wrong results) to expose the compute+barrier ceiling
     int splitk;      // > 1: blockIdx.y owns a K range and writes raw fp32 partials to ws[split][M][N]
     float* ws;
+    int sk_full;     // stream-K tail: tiles of the grouped order covered by the whole-round launch (0 = every tile, no tail)
+    int sk_tail;     //                tiles whose K loops the tail kernel spreads over the CUs
+    int sk_w;        //                K tiles per tail block
     int* counters;   // split-K: one arrival counter per output tile (zero on entry, left zero): the last K slice reduces in-kernel
     ConvGeom cv;
 };
@@ -973,13 +976,21 @@ __device__ __forceinline__ void glds_conv_one(const bf16* x, const ConvGeom& g, 
 
 // BN_ = 256: 2 x 4 waves of 128 x 64; BN_ = 128 (k-contiguous B only): 4 x 2 waves of 64 x 64 -- a 256 x 128 block tile for narrow
 // outputs (the 320-channel UNet layers are 3 x 128 = 83 % full instead of 2 x 256 = 62 %), same wave-level stream.
-template <int AL, int BL, int BN_ = 256>
-__global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+//
+// pipe_tile: the K loop of ONE output tile over the K tiles [kt0, kt1) (kt1 > kt0), accumulating into `acc`.  The whole-tile
+// kernel calls it with [0, K / 64); the stream-K tail kernel with a slice of a tile's K loop.
+template <int BN_>
+struct PipeGeom {
+    static constexpr int WC = BN_ / 64, MI = (256 / (8 / WC)) / 16;  // wave grid (8 / WC) x WC, MI 16-row MFMA tiles per wave
+};
+
+template <int AL, int BL, int BN_>
+__device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64_t m0, int64_t n0, int kt0, int kt1,
+                                          f32x4 (&acc)[PipeGeom<BN_>::MI][4]) {
     constexpr int T = 256, BM = T, BN = BN_;
     static_assert(BN == 256 || (BN == 128 && BL == B_K), "the 128-wide tile reads a k-contiguous B image");
     constexpr int TILE_BYTES = BM * BK * 2, TILE_B_BYTES = BN * BK * 2, STAGE = TILE_BYTES + TILE_B_BYTES;
-    constexpr int WC = BN / 64, MI = (BM / (8 / WC)) / 16;  // wave grid (8 / WC) x WC, MI 16-row MFMA tiles per wave
+    constexpr int WC = PipeGeom<BN_>::WC, MI = PipeGeom<BN_>::MI;
     constexpr int NBD = BN / 64;                            // DMA instructions per wave for the B tile (A: 4)
     constexpr int NG = 2 * MI;                              // MFMA groups per K tile
     constexpr bool AMC = (AL == A_M), BMC = (BL == B_N);
@@ -988,32 +999,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave / WC) * (MI * 16), wn = (wave % WC) * 64;
 
-    const int num_pid_m = (int)((P.M + BM - 1) / BM), num_pid_n = (int)((P.N + BN - 1) / BN);
-    const int nwg = num_pid_m * num_pid_n;
-    int wgid;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int GROUP_M = P.group_m > 0 ? P.group_m : 8;
-    const int in_group = GROUP_M * num_pid_n;
-    const int group_id = wgid / in_group;
-    const int first_m = group_id * GROUP_M;
-    const int gsz = min(num_pid_m - first_m, GROUP_M);
-    const int pid_m = first_m + (wgid % in_group) % gsz;
-    const int pid_n = (wgid % in_group) / gsz;
-    const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN;
-
-    f32x4 acc[MI][4];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     ConvDma cdma;
     if constexpr (AL == A_CONV) conv_dma_init(cdma, P.cv, m0, P.M, wave, lane);
-    int ctap = 0, cci = 0;  // conv: tap / first channel of the K tile being prefetched (advanced incrementally: no division)
+    // conv: tap / first channel of the K tile being prefetched (advanced incrementally: no division inside the loop)
+    int ctap = 0, cci = 0;
+    if constexpr (AL == A_CONV) {
+        if (kt0 != 0) {
+            ctap = (int)(((int64_t)kt0 * BK) / P.cv.C);
+            cci = (int)(((int64_t)kt0 * BK) % P.cv.C);
+        }
+    }
 
     auto issue = [&](int64_t k0, int buf) {
         char* ta = smem + buf * STAGE;
@@ -1071,16 +1066,16 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
         }
     };
 
-    const int nt = (int)(P.K / BK);
-    issue(0, 0);
+    issue((int64_t)kt0 * BK, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     first_reads();
 
-    for (int t = 0; t < nt; ++t) {
+    for (int t = kt0; t < kt1; ++t) {
         // tile t+1 goes into the buffer tile t-1 was read from: every wave finished those reads before the last barrier
-        const bool pf = (t + 1 < nt) && P.dbg_noload != 1;
+        const bool pf = (t + 1 < kt1) && P.dbg_noload != 1;
         const int64_t kpf = P.dbg_noload == 2 ? (int64_t)0 : (int64_t)(t + 1) * BK;
+        const int nbuf = (t - kt0 + 1) & 1;
         if constexpr (AL == A_CONV) {  // K tile t+1 starts BK channels further; wraps into the next tap at C
             cci += BK;
             if (cci >= P.cv.C) {
@@ -1091,7 +1086,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
         static_for<0, NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
             if constexpr (g < 4 + NBD) {  // one DMA instruction per group from the start of the tile: no 64-KiB burst per CU
-                if (pf) issue_one(kpf, (t + 1) & 1, g);
+                if (pf) issue_one(kpf, nbuf, g);
             }
             if constexpr (g < NG - 1) {
                 constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
@@ -1101,11 +1096,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
                 fragr_wait<OA + (in == 0 ? 4 * OB : 0)>(fa[g & 1]);
             } else {
                 fragr_wait<0>(fa[g & 1]);
-                if (t + 1 < nt) {
+                if (t + 1 < kt1) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
-                    ab = s0 + offA + (uint32_t)(((t + 1) & 1) * STAGE);
-                    bb = s0 + offB + (uint32_t)(((t + 1) & 1) * STAGE);
+                    ab = s0 + offA + (uint32_t)(nbuf * STAGE);
+                    bb = s0 + offB + (uint32_t)(nbuf * STAGE);
                     first_reads();
                 }
             }
@@ -1117,6 +1112,50 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
             __builtin_amdgcn_sched_barrier(0);
         });
     }
+}
+
+// Tile `wgid` of the grouped (GROUP_M) tile order -> (pid_m, pid_n)
+__device__ __forceinline__ void pipe_decode_tile(const GemmParams& P, int wgid, int num_pid_m, int num_pid_n, int& pid_m, int& pid_n) {
+    const int GROUP_M = P.group_m > 0 ? P.group_m : 8;
+    const int in_group = GROUP_M * num_pid_n;
+    const int group_id = wgid / in_group;
+    const int first_m = group_id * GROUP_M;
+    const int gsz = min(num_pid_m - first_m, GROUP_M);
+    pid_m = first_m + (wgid % in_group) % gsz;
+    pid_n = (wgid % in_group) / gsz;
+}
+
+template <int AL, int BL, int BN_ = 256>
+__global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 256, BN = BN_;
+    constexpr int WC = PipeGeom<BN_>::WC, MI = PipeGeom<BN_>::MI;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave / WC) * (MI * 16), wn = (wave % WC) * 64;
+
+    const int num_pid_m = (int)((P.M + BM - 1) / BM), num_pid_n = (int)((P.N + BN - 1) / BN);
+    // stream-K tail (sk_full > 0): this launch covers the first sk_full tiles of the grouped order (whole rounds of 256 CUs); the
+    // remaining tiles' K loops are spread evenly over the CUs by gemm_pipe_tail_kernel
+    const int nwg = P.sk_full > 0 ? P.sk_full : num_pid_m * num_pid_n;
+    int wgid;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int pid_m, pid_n;
+    pipe_decode_tile(P, wgid, num_pid_m, num_pid_n, pid_m, pid_n);
+    const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN;
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    pipe_tile<AL, BL, BN_>(P, smem, m0, n0, 0, (int)(P.K / BK), acc);
+
     if (epilogue_lds_ok(P, m0, n0, BM, BN)) {
         // every wave must be done with its fragment reads before the stages are reused as per-wave staging regions
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1125,6 +1164,96 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
     } else {
         gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane);
     }
+}
+
+// ---- stream-K tail of the pipelined kernel ---------------------------------------------------------------------------------
+// One 256 x 256 block per CU means a grid runs in rounds of 256 tiles; the weight gradients of the MLP have 1376 (gate|up) and 688
+// (down) tiles = 5.4 and 2.7 rounds, so their last round leaves 62 % / 31 % of the chip idle (10 % of those launches).  With a
+// workspace the launch is split: the whole rounds run as usual (gemm_pipe_kernel over the first sk_full tiles of the grouped
+// order); the K loops of the remaining sk_tail tiles are CONCATENATED into one iteration space of sk_tail * (K / 64) K tiles and
+// cut into equal contiguous ranges of sk_w K tiles, one per CU (a range covers the end of one tile and the start of the next: at
+// most two segments, because sk_w <= K / 64 when sk_tail <= 256).  Each segment's raw fp32 accumulators go to a workspace slab in
+// the thread-linear layout [(i, j)][tid] (8 KiB contiguous per store instruction); gemm_pipe_fixup_kernel sums a tile's slabs in
+// ascending K order (fixed order: deterministic, bit-identical run to run) and applies the ordinary epilogue.
+constexpr int64_t SK_SLAB_FLOATS = 256 * 256;
+constexpr int64_t SK_WS_BYTES = 2 * 256 * SK_SLAB_FLOATS * 4;  // two segments per tail block, 256 tail blocks: 128 MiB
+
+template <int AL, int BL>
+__global__ __launch_bounds__(512, 2) void gemm_pipe_tail_kernel(GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MI = 8;
+    const int tid = threadIdx.x;
+    const int num_pid_m = (int)((P.M + 255) / 256), num_pid_n = (int)((P.N + 255) / 256);
+    const int nt = (int)(P.K / BK);
+    const int64_t total = (int64_t)P.sk_tail * nt;
+    int64_t it0 = (int64_t)blockIdx.x * P.sk_w;
+    const int64_t it1 = min(it0 + (int64_t)P.sk_w, total);
+    for (int seg = 0; it0 < it1; ++seg) {
+        const int j = (int)(it0 / nt);
+        const int kt0 = (int)(it0 - (int64_t)j * nt);
+        const int kt1 = (int)min((int64_t)nt, (int64_t)kt0 + (it1 - it0));
+        int pid_m, pid_n;
+        pipe_decode_tile(P, P.sk_full + j, num_pid_m, num_pid_n, pid_m, pid_n);
+        f32x4 acc[MI][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pipe_tile<AL, BL, 256>(P, smem, (int64_t)pid_m * 256, (int64_t)pid_n * 256, kt0, kt1, acc);
+        float* slab = P.ws + ((int64_t)blockIdx.x * 2 + seg) * SK_SLAB_FLOATS;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(slab + ((int64_t)(i * 4 + q) * 512 + tid) * 4) = acc[i][q];
+        it0 += kt1 - kt0;
+        // the next segment's first DMA overwrites the LDS stages: every wave must have finished its fragment reads
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+}
+
+// one block per tail tile: sum the slabs of the tail blocks that covered its K loop, in K order, then the ordinary epilogue
+__global__ __launch_bounds__(512) void gemm_pipe_fixup_kernel(GemmParams P) {
+    constexpr int MI = 8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave / 4) * 128, wn = (wave % 4) * 64;
+    const int num_pid_m = (int)((P.M + 255) / 256), num_pid_n = (int)((P.N + 255) / 256);
+    const int nt = (int)(P.K / BK);
+    const int j = blockIdx.x;
+    int pid_m, pid_n;
+    pipe_decode_tile(P, P.sk_full + j, num_pid_m, num_pid_n, pid_m, pid_n);
+    const int64_t a = (int64_t)j * nt, b = a + nt - 1;
+    const int u0 = (int)(a / P.sk_w), u1 = (int)(b / P.sk_w);
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int u = u0; u <= u1; ++u) {
+        const int seg = ((int64_t)u * P.sk_w) / nt == j ? 0 : 1;  // the block's range starts in this tile (segment 0) or in the one before
+        const float* slab = P.ws + ((int64_t)u * 2 + seg) * SK_SLAB_FLOATS;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][q] += *reinterpret_cast<const f32x4*>(slab + ((int64_t)(i * 4 + q) * 512 + tid) * 4);
+    }
+    gemm_epilogue<MI>(P, acc, (int64_t)pid_m * 256 + wm, (int64_t)pid_n * 256 + wn, lane);
+}
+
+// Stream-K tail plan for an [M, N, K] problem on the 256 x 256 pipelined kernel: whole rounds first, the rest evenly over the CUs.
+// Returns false when there is nothing to gain (grid within one round, an almost full last round, a short K loop).
+static inline bool streamk_plan(int64_t M, int64_t N, int64_t K, int& full, int& tail, int& w, int& blocks) {
+    const int64_t tiles = cdiv64(M, 256) * cdiv64(N, 256);
+    const int64_t nt = K / BK;
+    const int64_t r = tiles % 256;
+    if (tiles <= 256 || tiles > 0x3fffffff || r == 0 || r > 224 || nt < 32) return false;
+    full = (int)(tiles - r);
+    tail = (int)r;
+    const int64_t total = r * nt;
+    w = (int)cdiv64(total, 256);
+    if (w < 8) return false;  // (cannot happen with nt >= 32 and r >= 1 ... kept as a guard for the pipeline depth)
+    blocks = (int)cdiv64(total, w);
+    return true;
 }
 
 template <int AL, int BL, int T>
@@ -1211,6 +1340,18 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
                 dllm_ensure_dyn_lds(&gemm_glds_kernel<AL, BL>, LDS, lds_ok);
                 if (V.glds_pipe) {
                     dllm_ensure_dyn_lds(&gemm_pipe_kernel<AL, BL>, LDS, lds2_ok);
+                    int full = 0, tail = 0, w = 0, blocks = 0;
+                    if (P.ws != nullptr && P.splitk <= 1 && P.dbg_noload == 0 && streamk_plan(P.M, P.N, P.K, full, tail, w, blocks)) {
+                        // whole rounds, then the last partial round's K loops spread evenly over the CUs, then the fix-up
+                        static std::atomic<uint64_t> lds3_ok{0};
+                        dllm_ensure_dyn_lds(&gemm_pipe_tail_kernel<AL, BL>, LDS, lds3_ok);
+                        GemmParams Q = P;
+                        Q.sk_full = full; Q.sk_tail = tail; Q.sk_w = w;
+                        hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)full), dim3(512), LDS, stream, Q);
+                        hipLaunchKernelGGL((gemm_pipe_tail_kernel<AL, BL>), dim3((unsigned)blocks), dim3(512), LDS, stream, Q);
+                        hipLaunchKernelGGL(gemm_pipe_fixup_kernel, dim3((unsigned)tail), dim3(512), 0, stream, Q);
+                        return dllm_check_launch();
+                    }
                     hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);
                     return dllm_check_launch();
                 }
@@ -1277,6 +1418,19 @@ int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bia
     if (layout_a == A_M && layout_b == B_N) return launch_gemm<A_M, B_N>(P, V, s);
     if (layout_a == A_M && layout_b == B_K) return launch_gemm<A_M, B_K>(P, V, s);
     return DLLM_ERR_SHAPE;
+}
+
+// Stream-K tail (splitk <= 1 and workspace != NULL): the workspace must hold dllm_gemm_streamk_ws_bytes() bytes; the library then
+// splits launches whose last round of 256 x 256 tiles would leave most of the chip idle (see gemm_pipe_tail_kernel).  Results are
+// deterministic (fixed summation order) and differ from the unsplit launch only by fp32 re-association of the K sum.
+int64_t dllm_gemm_streamk_ws_bytes(void) { return SK_WS_BYTES; }
+// 1 when dllm_gemm_bf16_splitk(..., splitk = 1, workspace != NULL, ...) would take the stream-K tail path for this problem
+int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int layout_b) {
+    if (M <= 0 || N <= 0 || K < BK || (K % BK) != 0) return 0;
+    if (layout_a == A_M && layout_b == B_K) return 0;
+    if (tile_eff(M, N, 256, 1.15) < tile_eff(M, N, 128, 0.85)) return 0;
+    int full, tail, w, blocks;
+    return streamk_plan(M, N, K, full, tail, w, blocks) ? 1 : 0;
 }
 
 // Split-K helper: number of K splits this library would like for an [M,N,K] problem (1 = none).  Small grids with a deep

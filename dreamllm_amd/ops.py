@@ -211,6 +211,27 @@ def layernorm_bwd(dy, x, w, mean, rstd, need_dw=True):
     return dx.view(x.shape), dw, db
 
 
+# Stream-K tail (include/dreamllm_hip.h): one 128 MiB fp32 workspace per device, handed to the GEMM when the library says the
+# problem's last round of tiles would otherwise leave most of the chip idle.  DREAMLLM_STREAMK=0 switches it off (A/B knob).
+STREAMK = os.environ.get("DREAMLLM_STREAMK", "1") != "0"
+_STREAMK_WS, _STREAMK_HINT = {}, {}
+
+
+def _streamk_hint(M, N, K, layout_a, layout_b):
+    key = (M, N, K, layout_a, layout_b)
+    h = _STREAMK_HINT.get(key)
+    if h is None:
+        h = _STREAMK_HINT[key] = bool(_lib.call("dllm_gemm_streamk_hint", M, N, K, layout_a, layout_b))
+    return h
+
+
+def _streamk_workspace(device):
+    ws = _STREAMK_WS.get(device)
+    if ws is None:
+        ws = _STREAMK_WS[device] = torch.empty(int(_lib.call("dllm_gemm_streamk_ws_bytes")) // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=torch.bfloat16, bias=None, residual=None,
          ldr=0, epi=None, accumulate=False, alpha=1.0):
     """C[M,N] = A*B; layout_a 0: A[m][k] k-contiguous, 1: stored [K][lda]; layout_b 0: B as [N][ldb], 1: [K][ldb]."""
@@ -220,6 +241,8 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
     sk = _lib.call("dllm_gemm_splitk_hint", M, N, K) if SPLITK else 1
     ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
+    if sk == 1 and STREAMK and (GEMM_VARIANT & 0xffff) in (0, 259) and _streamk_hint(M, N, K, layout_a, layout_b):
+        ws = _streamk_workspace(a.device)   # the library spreads the last partial round of 256-tiles over the CUs (stream-K tail)
     cnt = _splitk_counters(a.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-M // 128) * -(-N // 128) <= 16384) else None
     variant = GEMM_VARIANT
     if variant == 0 and sk == 1:

@@ -77,6 +77,14 @@ int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, cons
  * release/acquire around a ticket); NULL = a separate reduce kernel follows.  Use one counter array per stream in flight.
  * dllm_gemm_splitk_hint suggests splitk. */
 int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K);
+/* Stream-K tail of the 256 x 256 pipelined kernel: dllm_gemm_bf16_splitk(..., splitk = 1, workspace != NULL, ...) with a caller-owned
+ * workspace of dllm_gemm_streamk_ws_bytes() bytes lets launches whose LAST round of tiles would leave most of the 256 CUs idle (the
+ * MLP weight gradients: 1376 and 688 tiles = 5.4 / 2.7 rounds) run their whole rounds as usual and spread the K loops of the
+ * remaining tiles evenly over the CUs (fp32 partial slabs in the workspace, summed in fixed K order by a fix-up launch: deterministic).
+ * dllm_gemm_streamk_hint returns 1 when a problem would take that path (so the caller only hands over the workspace then).
+ * Replaces nothing in the reference (torch.nn.Linear backward -> cuBLAS picks its own split): a scheduling choice of this library. */
+int64_t dllm_gemm_streamk_ws_bytes(void);
+int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int layout_b);
 /* `variant` selects the kernel PER CALL (the library holds no mutable state; every entry point is re-entrant and may be called
  * from any thread on any stream): low 16 bits = tile family -- 0 automatic (what the product passes), 128 / 256 register-staged
  * tiles, 257 plain LDS-DMA 256-tile kernel, 259 software-pipelined LDS-DMA kernel (the automatic choice for eligible shapes);
