@@ -1241,17 +1241,22 @@ __global__ __launch_bounds__(512) void gemm_pipe_fixup_kernel(GemmParams P) {
 }
 
 // Stream-K tail plan for an [M, N, K] problem on the 256 x 256 pipelined kernel: whole rounds first, the rest evenly over the CUs.
-// Returns false when there is nothing to gain (grid within one round, an almost full last round, a short K loop).
+// Returns false when there is nothing to gain.  Measured on MI355X (tools/streamk_ab.py, profiles/r03_streamk_ab.log): the tail
+// blocks walk DIFFERENT K ranges of their tiles, so -- unlike the whole-tile rounds, where an XCD's 32 concurrent tiles share A / B
+// panels at the same K position through its L2 -- every tail block streams its own 64 KiB per K tile, and a tail that still fills
+// most of the chip is bandwidth-bound: the gate|up weight gradient (1376 tiles, remainder 96 = 37 % of a round, K = 32768) gains
+// 8.6 %, the down weight gradient (688 tiles, remainder 176 = 69 %) LOSES 4 %, the down input gradient (remainder 128, K = 4096:
+// the half round saved is 50 us, less than two extra launches and the slab traffic) loses 1 %.  Hence: remainder at most half a
+// round, and the idle share of that round worth at least 160 K tiles (~0.26 ms) of one CU.
 static inline bool streamk_plan(int64_t M, int64_t N, int64_t K, int& full, int& tail, int& w, int& blocks) {
     const int64_t tiles = cdiv64(M, 256) * cdiv64(N, 256);
     const int64_t nt = K / BK;
     const int64_t r = tiles % 256;
-    if (tiles <= 256 || tiles > 0x3fffffff || r == 0 || r > 224 || nt < 32) return false;
+    if (tiles <= 256 || tiles > 0x3fffffff || r == 0 || r > 128 || (256 - r) * nt < 160 * 256) return false;
     full = (int)(tiles - r);
     tail = (int)r;
     const int64_t total = r * nt;
     w = (int)cdiv64(total, 256);
-    if (w < 8) return false;  // (cannot happen with nt >= 32 and r >= 1 ... kept as a guard for the pipeline depth)
     blocks = (int)cdiv64(total, w);
     return true;
 }

@@ -138,9 +138,10 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = HipConv2d(cout, cout, 3)
         self.conv_shortcut = HipConv2d(cin, cout, 1) if cin != cout else None
 
-    def forward(self, x, emb_act):
-        """emb_act = SiLU(emb), shared by every ResBlock of the step."""
-        t = self.time_emb_proj(emb_act)
+    def forward(self, x, emb_act, time_bias=None):
+        """emb_act = SiLU(emb), shared by every ResBlock of the step.  `time_bias` [N, cout]: this block's `time_emb_proj(emb_act)`
+        computed ahead of the denoising loop (`HipUNet2DConditionModel.precompute_time_bias`); it does not depend on the latents."""
+        t = time_bias if time_bias is not None else self.time_emb_proj(emb_act)
         h = self.conv1(self.norm1(x), image_bias=t)
         sc = self.conv_shortcut(x) if self.conv_shortcut is not None else x
         return self.conv2(self.norm2(h), residual=sc)
@@ -362,6 +363,61 @@ class HipUNet2DConditionModel(nn.Module):
         ctx = encoder_hidden_states.to(self.dtype)
         return {id(t): [b.attn2.project_context(ctx) for b in t.transformer_blocks] for t in self._attn_modules()}
 
+    def _resnets(self):
+        """Every ResnetBlock2D in execution order (the layout of the precomputed time-bias buffer)."""
+        out = []
+        for blk in self.down_blocks:
+            out += list(blk.resnets)
+        out += list(self.mid_block.resnets)
+        for blk in self.up_blocks:
+            out += list(blk.resnets)
+        return out
+
+    def _embedding(self, timesteps, N, added_cond_kwargs=None):
+        """emb = time_embedding(sinusoid(t)) [+ add_embedding(text_embeds | sinusoid(time_ids))] for N samples."""
+        cfg = self.config
+        dev = timesteps.device
+        t_emb = timestep_embedding(timesteps, cfg.block_out_channels[0], cfg.flip_sin_to_cos, cfg.freq_shift).to(self.dtype)
+        emb = self.time_embedding(t_emb)
+        if cfg.addition_embed_type == "text_time":
+            te = timestep_embedding(added_cond_kwargs["time_ids"].flatten().to(dev), cfg.addition_time_embed_dim,
+                                    cfg.flip_sin_to_cos, cfg.freq_shift).reshape(N, -1).to(self.dtype)
+            add = torch.cat([added_cond_kwargs["text_embeds"].to(self.dtype), te], dim=-1)
+            emb = ops.add(emb, self.add_embedding(add))
+        return emb
+
+    def time_bias_layout(self, N):
+        """[(offset, cout)] of every ResBlock's [N, cout] slice in the flat time-bias buffer, and its total length."""
+        offs, off = [], 0
+        for r in self._resnets():
+            c = r.time_emb_proj.out_features
+            offs.append((off, c))
+            off += N * c
+        return offs, off
+
+    @torch.no_grad()
+    def precompute_time_bias(self, timesteps, N, added_cond_kwargs=None):
+        """The part of the UNet that depends on the TIMESTEP only -- sinusoid, time-embedding MLP, SiLU and every ResBlock's
+        `time_emb_proj` (~38 tiny launches per denoising step at SD-2.1 dims) -- for ALL steps of a loop at once: one GEMM per
+        ResBlock over M = len(timesteps) rows instead of one per step over M = N.  -> [S, total] bf16 table whose row s is the flat
+        buffer `forward(time_bias=...)` reads (`time_bias_layout`): per block [N, cout], the N images sharing the step's timestep.
+        Reference loop: modeling_plugins.py:809-821 (diffusers recomputes the embedding inside every UNet call)."""
+        ts = torch.as_tensor(timesteps, device=self.device).reshape(-1)
+        S = ts.numel()
+        if self.config.addition_embed_type == "text_time":
+            # the micro-conditioning rows differ per image: embed (step, image) pairs
+            emb = self._embedding(ts.repeat_interleave(N), S * N,
+                                  {k: v.repeat(S, *([1] * (v.dim() - 1))) for k, v in added_cond_kwargs.items()})   # [S*N, temb]
+        else:
+            emb = self._embedding(ts, S)                                                                                  # [S, temb]
+        emb_act = ops.silu(emb)
+        parts = []
+        for r in self._resnets():
+            tb = r.time_emb_proj(emb_act)                                   # [S or S*N, cout]
+            tb = tb.view(S, N, -1) if tb.shape[0] == S * N else tb[:, None, :].expand(S, N, tb.shape[-1])
+            parts.append(tb.reshape(S, -1))
+        return torch.cat(parts, dim=1).contiguous()
+
     @staticmethod
     def to_nhwc(x, cpad=None):
         x = x.permute(0, 2, 3, 1)
@@ -370,33 +426,34 @@ class HipUNet2DConditionModel(nn.Module):
         return x.contiguous()
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, context_cache=None, return_dict=True,
-                nhwc_io=False, **unused):
+                nhwc_io=False, time_bias=None, **unused):
         """sample: [N,4,H,W] (diffusers layout) or, with nhwc_io, [N,H,W,8] channel-padded NHWC; returns `.sample` in the
-        same layout family ([N,4,H,W] or [N,H,W,4])."""
+        same layout family ([N,4,H,W] or [N,H,W,4]).  `time_bias`: flat buffer of one row of `precompute_time_bias` (then
+        `timestep` / `added_cond_kwargs` are not read: everything they feed was computed ahead of the loop)."""
         cfg = self.config
         N = sample.shape[0]
         dev = sample.device
-        if not torch.is_tensor(timestep):
-            timestep = torch.tensor([timestep], device=dev)
-        timesteps = timestep.reshape(-1).to(dev).expand(N)
-        t_emb = timestep_embedding(timesteps, cfg.block_out_channels[0], cfg.flip_sin_to_cos, cfg.freq_shift).to(self.dtype)
-        emb = self.time_embedding(t_emb)
-        if cfg.addition_embed_type == "text_time":
-            te = timestep_embedding(added_cond_kwargs["time_ids"].flatten().to(dev), cfg.addition_time_embed_dim,
-                                    cfg.flip_sin_to_cos, cfg.freq_shift).reshape(N, -1).to(self.dtype)
-            add = torch.cat([added_cond_kwargs["text_embeds"].to(self.dtype), te], dim=-1)
-            kp = _pad8(add.shape[-1])
-            emb = ops.add(emb, self.add_embedding(add))
-        emb_act = ops.silu(emb)
+        tb_of = None
+        if time_bias is not None:
+            offs, total = self.time_bias_layout(N)
+            assert time_bias.numel() == total, "time_bias does not match this batch size"
+            tb_of = {id(r): time_bias[o:o + N * c].view(N, c) for r, (o, c) in zip(self._resnets(), offs)}
+            emb_act = None
+        else:
+            if not torch.is_tensor(timestep):
+                timestep = torch.tensor([timestep], device=dev)
+            timesteps = timestep.reshape(-1).to(dev).expand(N)
+            emb_act = ops.silu(self._embedding(timesteps, N, added_cond_kwargs))
         ctx = encoder_hidden_states.to(self.dtype)
         x = sample if nhwc_io else self.to_nhwc(sample.to(self.dtype), _pad8(cfg.in_channels))
         kvc = (lambda t: context_cache[id(t)]) if context_cache is not None else (lambda t: None)
+        tbo = (lambda r: tb_of[id(r)]) if tb_of is not None else (lambda r: None)
 
         x = self.conv_in(x)
         skips = [x]
         for blk in self.down_blocks:
             for j, r in enumerate(blk.resnets):
-                x = r(x, emb_act)
+                x = r(x, emb_act, tbo(r))
                 if hasattr(blk, "attentions"):
                     x = blk.attentions[j](x, ctx, kvc(blk.attentions[j]))
                 skips.append(x)
@@ -404,13 +461,13 @@ class HipUNet2DConditionModel(nn.Module):
                 x = blk.downsamplers[0](x)
                 skips.append(x)
         m = self.mid_block
-        x = m.resnets[0](x, emb_act)
+        x = m.resnets[0](x, emb_act, tbo(m.resnets[0]))
         x = m.attentions[0](x, ctx, kvc(m.attentions[0]))
-        x = m.resnets[1](x, emb_act)
+        x = m.resnets[1](x, emb_act, tbo(m.resnets[1]))
         for blk in self.up_blocks:
             for j, r in enumerate(blk.resnets):
                 x = torch.cat([x, skips.pop()], dim=-1)  # channel concat on NHWC: pure data movement
-                x = r(x, emb_act)
+                x = r(x, emb_act, tbo(r))
                 if hasattr(blk, "attentions"):
                     x = blk.attentions[j](x, ctx, kvc(blk.attentions[j]))
             if hasattr(blk, "upsamplers"):

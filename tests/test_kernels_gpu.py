@@ -226,6 +226,77 @@ def test_gemm_full_tile_epilogue_and_persistent_walk(variant, gemm_tile):
     assert float(err.max()) < 0.25, err
 
 
+@pytest.mark.parametrize("layout,M,N,K", [
+    ("fwd", 5632, 4096, 16384),    # 22 x 16 = 352 tiles: one whole round + 96 tail tiles (the gate|up weight gradient's remainder)
+    ("fwd", 6100, 4096, 20480),    # 24 x 16 = 384 tiles, ragged last row of tiles: 128 tail tiles
+    ("dgrad", 5632, 4096, 16384),
+    ("wgrad", 4096, 5632, 16384),  # dW[N=4096 x K'=5632] over T = 16384 tokens
+])
+def test_gemm_streamk_tail(layout, M, N, K):
+    """Stream-K tail of the pipelined 256-tile kernel (include/dreamllm_hip.h): whole rounds as usual, the last partial round's K
+    loops spread evenly over the CUs through fp32 slabs + a fix-up launch.  Against the fp32 product, against the unsplit launch
+    (same kernel, K sum re-associated in fp32 only), run-to-run bit-identical, with the epilogue variants the weight gradients use
+    (fp32 output with accumulate; bf16 output with bias + residual)."""
+    ops = _ops()
+    from dreamllm_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    rn = lambda *s, scale=1.0: (torch.randn(*s, device=DEV, generator=g) * scale).to(BF)
+    la, lb = {"fwd": (0, 0), "dgrad": (0, 1), "wgrad": (1, 1)}[layout]
+
+    def run(streamk, **kw):
+        ops.STREAMK = streamk
+        try:
+            if layout == "fwd":
+                return ops.linear_fwd(a, b, **kw)
+            if layout == "dgrad":
+                return ops.linear_dgrad(a, b)
+            return ops.linear_wgrad(a, b, **kw)
+        finally:
+            ops.STREAMK = True
+
+    sc = 1.0 / math.sqrt(K)
+    if layout == "fwd":
+        a, b = rn(M, K), rn(N, K, scale=sc)
+        ref = a.float() @ b.float().t()
+    elif layout == "dgrad":      # dx[M, N] = dy[M, K] W[K, N]
+        a, b = rn(M, K), rn(K, N, scale=sc)
+        ref = a.float() @ b.float()
+    else:                        # dW[M, N] = dy[T, M]^T x[T, N] with T = K
+        a, b = rn(K, M), rn(K, N, scale=sc)
+        ref = a.float().t() @ b.float()
+    assert _lib.call("dllm_gemm_streamk_hint", M, N, K, la, lb) == 1, "the shape must take the stream-K path"
+    y1 = run(True)
+    y0 = run(False)
+    assert rel_l2(y1, ref) < 4e-3 and rel_l2(y0, ref) < 4e-3
+    assert rel_l2(y1, y0.float()) < 2e-3                       # same products, fp32 re-association + one bf16 rounding
+    assert torch.equal(run(True), y1)                          # fixed summation order: deterministic
+    # no stale / missing tile anywhere (tail tiles come from the fix-up launch)
+    tm, tn = -(-y1.shape[0] // 256), -(-y1.shape[1] // 256)
+    e = torch.zeros(tm * 256, tn * 256, device=DEV)
+    e[:y1.shape[0], :y1.shape[1]] = (y1.float() - ref).abs()
+    assert float(e.view(tm, 256, tn, 256).amax(dim=(1, 3)).max()) < 0.05 * float(ref.abs().max())
+    if layout == "wgrad":      # fp32 accumulate epilogue through the fix-up kernel (the fused lm_head + CE accumulates dW like this)
+        acc = torch.ones(M, N, dtype=torch.float32, device=DEV)
+        run(True, out=acc, accumulate=True, out_dtype=torch.float32)
+        assert rel_l2(acc, ref + 1.0) < 1e-5
+    if layout == "fwd":        # bias + residual epilogue on the tail tiles
+        bias, res = rn(N), rn(M, N)
+        yb = run(True, bias=bias, residual=res)
+        assert rel_l2(yb, ref + bias.float() + res.float()) < 4e-3
+
+
+def test_gemm_streamk_hint_only_where_it_pays():
+    from dreamllm_amd import _lib
+    T, d, F_ = 32768, 4096, 11008
+    h = lambda M, N, K, la, lb: _lib.call("dllm_gemm_streamk_hint", M, N, K, la, lb)
+    assert h(2 * F_, d, T, 1, 1) == 1                                  # gate|up weight gradient: 1376 tiles = 5 rounds + 96 (measured +8.6 %)
+    assert h(d, F_, T, 1, 1) == 0                                      # down weight gradient: remainder 176 tiles, bandwidth-bound tail (-4 %)
+    assert h(T, F_, d, 0, 1) == 0                                      # down dgrad: remainder 128 but K = 4096: the half round is 50 us
+    assert h(T, d, d, 0, 0) == 0 and h(T, 2 * F_, d, 0, 0) == 0        # whole rounds: nothing to gain
+    assert h(3 * d, d, T, 1, 1) == 0 and h(256, 256, 4096, 0, 0) == 0
+    assert _lib.call("dllm_gemm_streamk_ws_bytes") == 2 * 256 * 256 * 256 * 4
+
+
 def test_gemm_rejects_bad_shapes():
     ops = _ops()
     x, w = rnd(8, 12).to(DEV), rnd(16, 12).to(DEV)  # K = 12 not a multiple of 8
