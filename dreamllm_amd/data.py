@@ -9,6 +9,7 @@ device->host sync each (`torch.where` / `nonzero` over `input_ids`, the mask red
   * `seqlens`      int32 [B]   valid tokens per (right-padded) row  -> the flash kernels' span, no `_upad_input`;
   * `dream_index`  int64 [N_dm * n_dream]   flat rows (into [B*S]) of the dream-query slots after each <dream_start>;
   * `image_index`  int64 [N_img * n_patch]  flat rows of the image-patch slots after each <im_start>;
+  * `loss_index`   int64 [n_valid]          flat rows whose shifted label is not -100 (the rows the LM loss is computed on);
 
 in the (batch, position) order in which the reference's Python loops visit the slots (modeling_dreamllm.py:1085-1098,
 1110-1139), so `DreamLLMForCausalMLM.forward(**batch)` runs sync-free.  Everything is computed on the CPU inside the DataLoader
@@ -82,6 +83,10 @@ class DataCollatorForDreamLLMDataset:
         lens = mask.sum(-1)
         if bool((mask == (torch.arange(mask.shape[1])[None] < lens[:, None])).all()):
             ex["seqlens"] = lens.to(torch.int32)
+        # rows of the flattened [B*S] batch whose SHIFTED label (labels[b, s+1]) carries a loss: the fused lm_head + CE runs on these only
+        lab = ex["labels"]
+        shift = torch.cat([lab[:, 1:], lab.new_full((lab.shape[0], 1), IGNORE_INDEX)], dim=1).reshape(-1)
+        ex["loss_index"] = torch.nonzero(shift != IGNORE_INDEX, as_tuple=False).flatten()
         ids = ex["input_ids"]
         if self.dream_start_id is not None and ex["images_dm"] is not None:
             ex["dream_index"], n = slot_indices(ids, self.dream_start_id, self.n_dream)

@@ -913,8 +913,10 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
 
     def forward(self, input_ids=None, images=None, images_dm=None, attention_mask=None, position_ids=None,
                 past_key_values=None, inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
-                output_hidden_states=None, return_dict=None, dream_index=None, image_index=None, seqlens=None, seqstart=None):
-        """modeling_dreamllm.py:1353-1509."""
+                output_hidden_states=None, return_dict=None, dream_index=None, image_index=None, seqlens=None, seqstart=None,
+                loss_index=None):
+        """modeling_dreamllm.py:1353-1509.  `loss_index` (optional, from the data pipeline: flat rows of [B*S] whose SHIFTED label is not
+        -100, ascending): the fused lm_head + CE then skips the rows that carry no loss (image / dream patch slots, padding)."""
         if input_ids is not None:
             assert (
                 input_ids.shape[1] <= self.config.max_position_embeddings
@@ -960,7 +962,7 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
             shift = torch.cat([labels[:, 1:], labels.new_full((B, 1), -100)], dim=1).reshape(-1)
             if getattr(self.config, "fused_lm_head_ce", True) and return_dict:
                 # fused lm_head + CE: loss (and, in the same pass, its gradients) without the [B,S,V] fp32 logits
-                lm_loss = ops.lm_head_ce(hidden_states.reshape(B * S, H), self.lm_head.weight, shift)
+                lm_loss = ops.lm_head_ce(hidden_states.reshape(B * S, H), self.lm_head.weight, shift, rows=loss_index)
                 hs, w = hidden_states.detach(), self.lm_head.weight
                 lazy_logits = lambda: ops.linear_fwd(hs, ops._pad_vocab(w.detach()), out_dtype=torch.float32)[..., : w.shape[0]]  # noqa: E731
             else:

@@ -86,7 +86,7 @@ class DreamLLMSDXLForCausalMLM(DreamLLMForCausalMLM):
 
     def forward(self, input_ids=None, images=None, images_dm=None, add_time_ids=None, attention_mask=None, position_ids=None,
                 past_key_values=None, inputs_embeds=None, labels=None, use_cache=None, output_attentions=None,
-                output_hidden_states=None, return_dict=None, dream_index=None, image_index=None, seqlens=None):
+                output_hidden_states=None, return_dict=None, dream_index=None, image_index=None, seqlens=None, loss_index=None):
         """modeling_dreamllm_sdxl.py:1353-1509; `add_time_ids`: [N_dm, 6] = original_size + crop_top_left + target_size
         per dream image, as `SDXLDataProcessor` returns them."""
         self._add_time_ids = add_time_ids
@@ -95,6 +95,6 @@ class DreamLLMSDXLForCausalMLM(DreamLLMForCausalMLM):
                                    position_ids=position_ids, past_key_values=past_key_values, inputs_embeds=inputs_embeds,
                                    labels=labels, use_cache=use_cache, output_attentions=output_attentions,
                                    output_hidden_states=output_hidden_states, return_dict=return_dict, dream_index=dream_index,
-                                   image_index=image_index, seqlens=seqlens)
+                                   image_index=image_index, seqlens=seqlens, loss_index=loss_index)
         finally:
             self._add_time_ids = None

@@ -934,6 +934,8 @@ class LMHeadCEFn(torch.autograd.Function):
                 if dw32 is None:
                     dw32 = torch.empty(Vp, d, dtype=torch.float32, device=hidden.device)
                 linear_wgrad(dl_c, h_c, out=dw32, accumulate=i > 0, out_dtype=torch.float32)
+        if need_dw and dw32 is None:   # no rows at all (a batch without a single labelled token): the gradient is zero, not absent
+            dw32 = torch.zeros(Vp, d, dtype=torch.float32, device=hidden.device)
         dw = dw32[:V].to(weight.dtype) if dw32 is not None else None
         ctx.save_for_backward(dh, dw)
         return loss_rows.sum() / denom
@@ -987,10 +989,16 @@ class LMHeadCELogitsFn(torch.autograd.Function):
         return dh, dw, None
 
 
-def lm_head_ce(hidden2d, weight, labels1d, return_logits=False):
-    """-> loss (fused, no [T,V] tensor) or (loss, fp32 logits) with `return_logits=True` (unfused)."""
+def lm_head_ce(hidden2d, weight, labels1d, return_logits=False, rows=None):
+    """-> loss (fused, no [T,V] tensor) or (loss, fp32 logits) with `return_logits=True` (unfused).
+    `rows` (int64, unique, ascending: the rows whose label is not -100, from the data pipeline): the fused unit then runs on those
+    rows only -- ignored rows (image / dream patch slots, padding: a third of an interleaved document) contribute neither to the
+    loss nor to any gradient, so their logits are never computed.  Same loss, same gradients (zero rows of dHidden)."""
     if return_logits:
         return LMHeadCELogitsFn.apply(hidden2d, weight, labels1d)
+    if rows is not None:
+        hidden2d = gather_rows_unique(hidden2d, rows)   # backward: scatter into a zero [T, d]
+        labels1d = labels1d[rows]
     return LMHeadCEFn.apply(hidden2d, weight, labels1d, torch.is_grad_enabled())
 
 

@@ -47,6 +47,7 @@ def make_interleaved_batch(batch_size=16, seq_len=2048, images_per_sample=2, n_d
         labels[ids == add[t]] = -100
     labels[mask == 0] = -100
     dpos, ipos = torch.tensor(dream_pos), torch.tensor(image_pos)
+    shift = torch.cat([labels[:, 1:], labels.new_full((batch_size, 1), -100)], dim=1).reshape(-1)
     batch = dict(
         input_ids=ids.to(device), attention_mask=mask.to(device), labels=labels.to(device),
         dream_index=(dpos[:, None] + 1 + torch.arange(n_dream)[None]).reshape(-1).to(device),
@@ -54,6 +55,8 @@ def make_interleaved_batch(batch_size=16, seq_len=2048, images_per_sample=2, n_d
         # valid tokens per (right-padded) row, as data.DataCollatorForDreamLLMDataset emits them: the step then needs no
         # device->host sync to validate / reduce the mask
         seqlens=mask.sum(-1).to(torch.int32).to(device),
+        # rows whose shifted label carries a loss (data.DataCollatorForDreamLLMDataset emits the same key)
+        loss_index=torch.nonzero(shift != -100, as_tuple=False).flatten().to(device),
     )
     if with_pixels:
         n_img = batch_size * K

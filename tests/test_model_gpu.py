@@ -390,6 +390,20 @@ def test_collator_indices_match_the_model_path(golden):
     bare = {k: v for k, v in full.items() if k not in ("seqlens", "dream_index", "image_index")}
     b = lm(**bare, return_dict=True)
     assert torch.equal(a.loss, b.loss) and torch.equal(a.logits, b.logits)
+    # `loss_index` (rows whose shifted label carries a loss): the fused lm_head + CE skips the ignored rows -- same loss and the same
+    # gradients as scoring every row (the ignored rows contribute exact zeros); only the fp32 summation order over rows changes
+    shift = torch.cat([batch["labels"][:, 1:], torch.full((ids.shape[0], 1), -100)], 1).reshape(-1)
+    assert torch.equal(batch["loss_index"], torch.nonzero(shift != -100).flatten()) and 0 < batch["loss_index"].numel() < shift.numel()
+    lm.zero_grad(set_to_none=True)
+    a.loss.backward()
+    ga = {n: p.grad.clone() for n, p in lm.named_parameters() if p.grad is not None}
+    lm.zero_grad(set_to_none=True)
+    c = lm(**{k: v for k, v in full.items() if k != "loss_index"}, return_dict=True)
+    c.loss.backward()
+    assert abs(float(a.loss) - float(c.loss)) <= 1e-6 * abs(float(c.loss)) and torch.equal(a.logits, c.logits)
+    for n, p in lm.named_parameters():
+        if p.grad is not None:
+            assert rel_l2(ga[n], p.grad) < 2e-3, n   # (lm_head dW: fp32 chunk sums in a different order, then one bf16 rounding)
 
 
 @pytest.mark.parametrize("n_kv", [2, 1])
