@@ -111,3 +111,18 @@ static inline void dllm_ensure_dyn_lds(K kernel, int bytes, std::atomic<uint64_t
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     done.fetch_or(bit, std::memory_order_release);
 }
+
+// Number of compute units of the current device (256 on MI355X), cached per device ordinal; idempotent like the helper above.
+static inline int dllm_num_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int v = cached[dev & 63].load(std::memory_order_acquire);
+    if (v > 0) return v;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    n = (n / 8) * 8;  // whole blocks per XCD
+    if (n < 8) n = 8;
+    cached[dev & 63].store(n, std::memory_order_release);
+    return n;
+}

@@ -41,6 +41,7 @@ struct Variant {
     int dbg_noload = 0;  // benchmark-only wrong-result modes; compiled in with -DDLLM_BENCH_MODES only
     int group_m = 0;     // 0: per-layout default
     int force_n128 = 0;  // tile code 262: the 256 x 128 pipelined kernel wherever it is eligible (tests)
+    int persist = 0;     // bit 24: XCD-synchronised persistent walk of the pipelined 256-tile kernel (needs the workspace)
 };
 static inline int parse_variant(int variant, Variant& v) {
     const int tile = variant & 0xffff;
@@ -50,7 +51,8 @@ static inline int parse_variant(int variant, Variant& v) {
     ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265;
     v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
 #endif
-    if (!ok || (variant >> 24) != 0) return DLLM_ERR_SHAPE;
+    if (!ok || (variant >> 25) != 0) return DLLM_ERR_SHAPE;
+    v.persist = (variant >> 24) & 1;
     v.use_glds = (tile == 0 || tile >= 257);
     v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 262 || tile == 263 || tile == 265);
     v.force_tile = tile >= 257 ? 256 : tile;
@@ -1166,6 +1168,69 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
     }
 }
 
+// ---- XCD-synchronised persistent walk ----------------------------------------------------------------------------------------
+// One block per CU; the hardware deals block b to XCD b & 7.  Block (xcd, slot) walks tiles xcd_start + slot + 32 r of the grouped
+// order, r = 0, 1, ... -- the same 32-tile clusters per XCD as the one-tile-per-block launch -- but the 32 blocks of an XCD start
+// every tile TOGETHER (a counter in global memory, all 32 on the same L2): a cluster's tiles then move through K in lockstep and
+// share their A / B panels through the XCD's 4 MiB L2 (32 tiles need 12 panels x 32 KiB per K step when aligned).  Without it the
+// blocks of later rounds start whenever a CU frees up, drift apart by more than the ~10 K steps the L2 can bridge and re-fetch the
+// panels from the fabric (PMC: 12.6 GB fetched for the packed gate|up forward against 8.5 GB for aligned clusters).  The barrier
+// carries no data dependency: a block that waits "too long" (spin limit) simply goes on, so a missing co-resident block cannot hang it.
+__device__ __forceinline__ void xcd_barrier(unsigned* counter, unsigned target) {
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; spin < (1 << 16); ++spin) {
+            if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+    __syncthreads();
+}
+
+template <int AL, int BL>
+__global__ __launch_bounds__(512, 2) void gemm_pipe_persist_kernel(GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int MI = 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave / 4) * 128, wn = (wave % 4) * 64;
+    const int num_pid_m = (int)((P.M + 255) / 256), num_pid_n = (int)((P.N + 255) / 256);
+    const int nwg = P.sk_full > 0 ? P.sk_full : num_pid_m * num_pid_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;   // per = co-resident blocks per XCD (32)
+    const int q = nwg >> 3, r8 = nwg & 7;
+    const int start = xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q;
+    const int count = q + (xcd < r8 ? 1 : 0);
+    const int rounds = (count + per - 1) / per;
+    unsigned* counter = reinterpret_cast<unsigned*>(P.ws) + xcd * 16;                 // one 64-byte line per XCD
+    for (int r = 0; r < rounds; ++r) {
+        if (r > 0) xcd_barrier(counter, (unsigned)(per * r));   // round 0: the launch itself started the blocks together
+        const int it = r * per + slot;
+        if (it >= count) continue;
+        int pid_m, pid_n;
+        pipe_decode_tile(P, start + it, num_pid_m, num_pid_n, pid_m, pid_n);
+        const int64_t m0 = (int64_t)pid_m * 256, n0 = (int64_t)pid_n * 256;
+        f32x4 acc[MI][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        pipe_tile<AL, BL, 256>(P, smem, m0, n0, 0, (int)(P.K / BK), acc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // fragment reads done: the stages become epilogue staging, then the next tile's first DMA target
+        if (epilogue_lds_ok(P, m0, n0, 256, 256))
+            gemm_epilogue_lds<MI>(P, acc, smem + wave * 8192, m0 + wm, n0 + wn, lane);
+        else
+            gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave's staging reads are done before the next tile's DMA overwrites the stages
+    }
+    // leave the counter at zero for the next launch: every block arrives once more; the last arrival of the launch resets it
+    if (rounds > 1 && tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(per * rounds) - 1u) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---- stream-K tail of the pipelined kernel ---------------------------------------------------------------------------------
 // One 256 x 256 block per CU means a grid runs in rounds of 256 tiles; the weight gradients of the MLP have 1376 (gate|up) and 688
 // (down) tiles = 5.4 and 2.7 rounds, so their last round leaves 62 % / 31 % of the chip idle (10 % of those launches).  With a
@@ -1176,7 +1241,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
 // the thread-linear layout [(i, j)][tid] (8 KiB contiguous per store instruction); gemm_pipe_fixup_kernel sums a tile's slabs in
 // ascending K order (fixed order: deterministic, bit-identical run to run) and applies the ordinary epilogue.
 constexpr int64_t SK_SLAB_FLOATS = 256 * 256;
-constexpr int64_t SK_WS_BYTES = 2 * 256 * SK_SLAB_FLOATS * 4;  // two segments per tail block, 256 tail blocks: 128 MiB
+constexpr int64_t SK_HEAD_FLOATS = 1024;  // first 4 KiB of the workspace: per-XCD counters of the persistent walk (zero between launches)
+constexpr int64_t SK_WS_BYTES = (2 * 256 * SK_SLAB_FLOATS + SK_HEAD_FLOATS) * 4;  // two segments per tail block, 256 tail blocks: 128 MiB
 
 template <int AL, int BL>
 __global__ __launch_bounds__(512, 2) void gemm_pipe_tail_kernel(GemmParams P) {
@@ -1200,7 +1266,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_tail_kernel(GemmParams P) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
         pipe_tile<AL, BL, 256>(P, smem, (int64_t)pid_m * 256, (int64_t)pid_n * 256, kt0, kt1, acc);
-        float* slab = P.ws + ((int64_t)blockIdx.x * 2 + seg) * SK_SLAB_FLOATS;
+        float* slab = P.ws + SK_HEAD_FLOATS + ((int64_t)blockIdx.x * 2 + seg) * SK_SLAB_FLOATS;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1231,7 +1297,7 @@ __global__ __launch_bounds__(512) void gemm_pipe_fixup_kernel(GemmParams P) {
         for (int q = 0; q < 4; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int u = u0; u <= u1; ++u) {
         const int seg = ((int64_t)u * P.sk_w) / nt == j ? 0 : 1;  // the block's range starts in this tile (segment 0) or in the one before
-        const float* slab = P.ws + ((int64_t)u * 2 + seg) * SK_SLAB_FLOATS;
+        const float* slab = P.ws + SK_HEAD_FLOATS + ((int64_t)u * 2 + seg) * SK_SLAB_FLOATS;
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1346,18 +1412,29 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
                 if (V.glds_pipe) {
                     dllm_ensure_dyn_lds(&gemm_pipe_kernel<AL, BL>, LDS, lds2_ok);
                     int full = 0, tail = 0, w = 0, blocks = 0;
+                    // XCD-synchronised persistent walk (opt-in, variant bit 24): grids of at least 4 rounds, workspace present
+                    static std::atomic<uint64_t> lds4_ok{0};
+                    const bool persist = V.persist && P.ws != nullptr && P.splitk <= 1 && P.dbg_noload == 0 && tiles256 >= 1024;
+                    auto launch_main = [&](const GemmParams& Q, int64_t ntiles) {
+                        if (persist) {
+                            dllm_ensure_dyn_lds(&gemm_pipe_persist_kernel<AL, BL>, LDS, lds4_ok);
+                            hipLaunchKernelGGL((gemm_pipe_persist_kernel<AL, BL>), dim3((unsigned)dllm_num_cus()), dim3(512), LDS, stream, Q);
+                        } else {
+                            hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)ntiles), dim3(512), LDS, stream, Q);
+                        }
+                    };
                     if (P.ws != nullptr && P.splitk <= 1 && P.dbg_noload == 0 && streamk_plan(P.M, P.N, P.K, full, tail, w, blocks)) {
                         // whole rounds, then the last partial round's K loops spread evenly over the CUs, then the fix-up
                         static std::atomic<uint64_t> lds3_ok{0};
                         dllm_ensure_dyn_lds(&gemm_pipe_tail_kernel<AL, BL>, LDS, lds3_ok);
                         GemmParams Q = P;
                         Q.sk_full = full; Q.sk_tail = tail; Q.sk_w = w;
-                        hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)full), dim3(512), LDS, stream, Q);
+                        launch_main(Q, full);
                         hipLaunchKernelGGL((gemm_pipe_tail_kernel<AL, BL>), dim3((unsigned)blocks), dim3(512), LDS, stream, Q);
                         hipLaunchKernelGGL(gemm_pipe_fixup_kernel, dim3((unsigned)tail), dim3(512), 0, stream, Q);
                         return dllm_check_launch();
                     }
-                    hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);
+                    launch_main(P, tiles256);
                     return dllm_check_launch();
                 }
                 hipLaunchKernelGGL((gemm_glds_kernel<AL, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);

@@ -226,10 +226,18 @@ def _streamk_hint(M, N, K, layout_a, layout_b):
 
 
 def _streamk_workspace(device):
-    ws = _STREAMK_WS.get(device)
+    """One workspace per (device, stream): two GEMMs in flight on different streams must not share slabs / counters.  Zero-filled
+    once: its first 4 KiB are the per-XCD counters of the persistent walk, which every launch leaves at zero."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _STREAMK_WS.get(key)
     if ws is None:
-        ws = _STREAMK_WS[device] = torch.empty(int(_lib.call("dllm_gemm_streamk_ws_bytes")) // 4, dtype=torch.float32, device=device)
+        ws = _STREAMK_WS[key] = torch.zeros(int(_lib.call("dllm_gemm_streamk_ws_bytes")) // 4, dtype=torch.float32, device=device)
     return ws
+
+
+# XCD-synchronised persistent walk of the pipelined 256-tile kernel (csrc/gemm.hip: gemm_pipe_persist_kernel): opt-in per call through
+# bit 24 of `variant`; DREAMLLM_GEMM_PERSIST=1 / ops.GEMM_PERSIST turn it on for grids of >= 4 rounds of 256-tiles.
+GEMM_PERSIST = os.environ.get("DREAMLLM_GEMM_PERSIST", "0") == "1"
 
 
 def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=torch.bfloat16, bias=None, residual=None,
@@ -241,15 +249,20 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
     sk = _lib.call("dllm_gemm_splitk_hint", M, N, K) if SPLITK else 1
     ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
-    if sk == 1 and STREAMK and (GEMM_VARIANT & 0xffff) in (0, 259) and _streamk_hint(M, N, K, layout_a, layout_b):
-        ws = _streamk_workspace(a.device)   # the library spreads the last partial round of 256-tiles over the CUs (stream-K tail)
+    persist = 0
+    if sk == 1 and (GEMM_VARIANT & 0xffff) in (0, 259) and not torch.cuda.is_current_stream_capturing():
+        if STREAMK and _streamk_hint(M, N, K, layout_a, layout_b):
+            ws = _streamk_workspace(a.device)   # the library spreads the last partial round of 256-tiles over the CUs (stream-K tail)
+        if GEMM_PERSIST and -(-M // 256) * -(-N // 256) >= 1024 and K % 64 == 0:
+            ws = _streamk_workspace(a.device)
+            persist = 1 << 24
     cnt = _splitk_counters(a.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-M // 128) * -(-N // 128) <= 16384) else None
     variant = GEMM_VARIANT
     if variant == 0 and sk == 1:
         gm = _GROUP_M_TABLE.get((layout_a, layout_b, M, N, K), 0)
         if gm == 0 and GEMM_TUNE_GROUP_M and 2.0 * M * N * K >= _TUNE_MIN_FLOPS:   # opt-in tool, off in the product path
             gm = _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha)
-        variant = gm << 16
+        variant = (gm << 16) | persist
     with _GemmTimer(2.0 * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
         check("dllm_gemm_bf16_splitk", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
               ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),

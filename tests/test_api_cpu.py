@@ -288,3 +288,20 @@ def test_lazy_logits_keep_the_model_output_contract():
     assert o.logits is o["logits"] and len(calls) == n      # materialised once
     eager = CausalLMOutputWithPast(loss=torch.tensor(1.0), logits=torch.zeros(1), past_key_values=((1,),))
     assert list(eager.keys()) == ["loss", "logits", "past_key_values"]
+
+
+def test_rope_scaling_variants_match_the_executed_reference(golden):
+    """`rope_scaling = {"type": "linear" | "dynamic", "factor": f}` (modeling_dreamllm.py:131-173, selected at :279-304): the cos / sin
+    tables of `RotaryEmbedding.forward` against the executed reference classes, in a call order that includes sequences beyond
+    `max_position_embeddings` and shorter ones afterwards (the reference keeps serving the table it rebuilt for the longest
+    sequence seen; dynamic NTK therefore depends on the call history, and so does this implementation)."""
+    from dreamllm_amd.modeling_dreamllm import RotaryEmbedding
+    g = golden("rope_scaling.pt")
+    x = torch.zeros(1, 1, 1, g["dim"])
+    for c in g["cases"]:
+        rot = RotaryEmbedding(g["dim"], g["max_position_embeddings"], base=g["base"], scaling_factor=c["factor"],
+                              scaling_type=None if c["type"] == "none" else c["type"])
+        for st in c["steps"]:
+            cos, sin = rot(x, seq_len=st["seq_len"])
+            assert cos.shape == st["cos"].shape
+            assert (cos - st["cos"]).abs().max() < 2e-5 and (sin - st["sin"]).abs().max() < 2e-5, (c["type"], c["factor"], st["seq_len"])
