@@ -396,6 +396,10 @@ class DreamLLMAttention(nn.Module):
 DreamLLMFlashAttention2 = DreamLLMAttention  # same module: flash semantics are the only execution path
 
 
+class _MaskHasHoles(ValueError):
+    """A 2-D mask whose valid tokens are not one contiguous run per row (see `_mask_to_spans`)."""
+
+
 def _mask_to_spans(attention_mask, q_len=None):
     """2-D padding mask [B, Sk] -> (seqstart, seqlens): int32 [B] device tensors (or None) describing the ONE contiguous run
     of valid tokens of every row, which is what the flash kernels take instead of the reference's unpad / pad round trip
@@ -406,8 +410,10 @@ def _mask_to_spans(attention_mask, q_len=None):
       projects/dreamllm/cli_stable_diffusion_pipeline.py:19): start = number of pad tokens in front;
     * `q_len < Sk` (a KV cache is attached): the run has to reach the last key -- the new tokens are valid by
       construction -- and only `seqstart` is returned.
-    A mask with holes or more than one run cannot be expressed and raises ValueError (the reference's eager path would
-    honour it; silently attending to pad tokens is never an option).  A 4-D additive mask is rejected.  The check reads
+    A mask with holes or more than one run cannot be expressed as a span and raises `_MaskHasHoles` (a ValueError):
+    `DreamLLMModel._forward` then takes the compaction path (valid tokens gathered to the front in order, original positions kept
+    for RoPE -- what `_upad_input` / `pad_input` do around the reference's flash kernel, modeling_dreamllm.py:523-545,553-583);
+    silently attending to pad tokens is never an option.  A 4-D additive mask is rejected.  The check reads
     one flag back from the device (skipped under stream capture); callers that already know the spans pass
     `seqlens=` / `seqstart=` instead of a mask and stay sync-free (bench.py, data.collate_interleaved)."""
     if attention_mask is None:
@@ -425,8 +431,8 @@ def _mask_to_spans(attention_mask, q_len=None):
         flags = torch.stack([(run == m).all(), (start == 0).all(), (lens == Sk).all(),
                              ((start + lens == Sk) | (lens == 0)).all()]).tolist()
         if not flags[0]:
-            raise ValueError("attention_mask must mark ONE contiguous run of valid tokens per row (left or right padding); "
-                             "masks with holes are not supported by the flash-attention path")
+            raise _MaskHasHoles("attention_mask must mark ONE contiguous run of valid tokens per row (left or right padding) "
+                                "when a KV cache is attached; masks with holes are only supported without a cache")
         if with_cache and not flags[3]:
             raise ValueError("with past_key_values the valid keys must extend to the newest token (left padding only)")
         if flags[1] and flags[2]:
@@ -717,11 +723,27 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
             inputs_embeds = self.embed(input_ids)
         if position_ids is None and past_len > 0:
             position_ids = torch.arange(past_len, seq_length + past_len, dtype=torch.long, device=inputs_embeds.device)[None]
+        unperm_order = None
         if seqlens is None and seqstart is None and attention_mask is not None:
             if attention_mask.shape[-1] != seq_length + past_len:
                 raise ValueError(f"attention_mask covers {attention_mask.shape[-1]} positions, expected past + new = "
                                  f"{past_len} + {seq_length} (modeling_dreamllm.py:960-967)")
-            seqstart, seqlens = _mask_to_spans(attention_mask, q_len=seq_length)  # once per forward, not per layer
+            try:
+                seqstart, seqlens = _mask_to_spans(attention_mask, q_len=seq_length)  # once per forward, not per layer
+            except _MaskHasHoles:
+                if past_len > 0 or use_cache:
+                    raise
+                # masks with holes (`_get_unpad_data`, modeling_dreamllm.py:69-74, handles any 0/1 mask): compact every row's valid
+                # tokens to the front, in order; they keep their ORIGINAL positions for RoPE (position_ids default to arange,
+                # :950-955, independent of the mask); run the decoder on the right-padded compact batch; un-permute at the end.
+                # Rows at masked positions are don't-care in the reference as well (the loss never reads them).
+                valid = attention_mask != 0
+                unperm_order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)
+                pos = (position_ids if position_ids is not None else
+                       torch.arange(seq_length, device=inputs_embeds.device)[None]).expand(batch_size, seq_length)
+                position_ids = torch.gather(pos, 1, unperm_order)
+                inputs_embeds = torch.gather(inputs_embeds, 1, unperm_order[:, :, None].expand(-1, -1, inputs_embeds.shape[-1]))
+                seqstart, seqlens = None, valid.sum(-1, dtype=torch.int32).contiguous()
             attention_mask = None
         if self.training and use_cache:
             use_cache = False
@@ -742,6 +764,11 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
         hidden_states = self.norm(hidden_states)
         if output_hidden_states:
             all_hidden_states += (hidden_states,)
+        if unperm_order is not None:  # back to the caller's token order
+            back = lambda t: torch.zeros_like(t).scatter_(1, unperm_order[:, :, None].expand(-1, -1, t.shape[-1]), t)  # noqa: E731
+            hidden_states = back(hidden_states)
+            if output_hidden_states:
+                all_hidden_states = tuple(back(t) for t in all_hidden_states)
         next_cache = next_decoder_cache if use_cache else None
         if not return_dict:
             return tuple(v for v in [hidden_states, next_cache, all_hidden_states, None, additional_log_info] if v is not None)

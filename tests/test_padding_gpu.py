@@ -259,3 +259,34 @@ def test_holey_and_right_padded_cache_masks_raise():
     out = lm(input_ids=ids, attention_mask=am, use_cache=True, return_dict=True)  # right padding alone is fine
     with pytest.raises(ValueError):  # ... but a right-padded prompt followed by new tokens leaves a hole
         lm(input_ids=ids[:, :1], attention_mask=torch.cat([am, am.new_ones(2, 1)], 1), past_key_values=out.past_key_values)
+
+
+def test_mask_with_holes_matches_the_eager_oracle():
+    """A 0/1 mask whose valid tokens are NOT one run per row (`_get_unpad_data`, modeling_dreamllm.py:69-74, takes any mask; the
+    eager path the reference runs on this box honours it through the 4-D additive mask, :960-967): the HIP model compacts the
+    valid tokens, keeps their original RoPE positions and un-permutes the result.  Hidden states at the VALID positions against
+    the fp32 oracle with the oracle-in-bf16 yard-stick; no cache (a cache of a compacted batch is rejected)."""
+    from dreamllm_amd.factory import TINY, build_dreamllm
+    from oracle import llm_ref
+    torch.manual_seed(0)
+    lm = build_dreamllm(TINY, device=DEV, dtype=BF, with_clip=False, with_sd=False).eval()
+    B, S = 3, 96
+    ids = torch.randint(3, 1000, (B, S), device=DEV)
+    am = (torch.rand(B, S, device=DEV) > 0.3).long()
+    am[:, 0] = 1
+    am[1] = 1                       # one dense row
+    am[2, 40:] = 0                  # one row with holes AND right padding
+    with torch.no_grad():
+        out = lm.model(input_ids=ids, attention_mask=am, use_cache=False, return_dict=True).last_hidden_state
+    sd = {k: v.detach().float().cpu() for k, v in lm.state_dict().items()}
+    cfg = lm.config
+    cd = dict(num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+              num_key_value_heads=cfg.num_key_value_heads, rms_norm_eps=cfg.rms_norm_eps,
+              max_position_embeddings=cfg.max_position_embeddings, rope_theta=cfg.rope_theta)
+    emb = torch.nn.functional.embedding(ids.cpu(), sd["model.embed_tokens.weight"])
+    ref = llm_ref.model_forward(emb, sd, cd, attention_mask=am.cpu())
+    yard = llm_ref.model_forward(emb.to(BF), {k: v.to(BF) for k, v in sd.items()}, cd, attention_mask=am.cpu()).float()
+    m = am.bool().cpu()
+    check_tensor("padding.mask_with_holes.hidden", out.float().cpu()[m], ref[m], rel_l2(yard[m], ref[m]))
+    with pytest.raises(ValueError):     # a KV cache of the compacted batch would not line up with the caller's positions
+        lm.model(input_ids=ids, attention_mask=am, use_cache=True)
