@@ -38,8 +38,10 @@ def _worker(rank, world, port, q, mode="ddp", backend="gloo"):
     dev = torch.device("cuda", local)
     model = build_dreamllm(TINY, device=dev, seed=0, clip=dict(TINY_CLIP, num_hidden_layers=2), diffusion=TINY_DIFFUSION,
                            num_dream_queries=8).train()
+    tl = None
     if mode == "ddp":
-        ddp = D.wrap_ddp(model, bucket_cap_mb=1)
+        tl = D.BucketTimeline()          # the comm hook bench.py installs for N > 1: same all-reduce(mean) + per-bucket ready / done stamps
+        ddp = D.wrap_ddp(model, bucket_cap_mb=1, timeline=tl)
         assert ddp is not model
         opt = HipAdamW([p for p in model.parameters() if p.requires_grad], lr=1e-3, max_grad_norm=1.0)
     else:  # sharded-gradient mode: plain replica forward/backward, reduce-scatter + sharded AdamW + all-gather in the step
@@ -59,6 +61,10 @@ def _worker(rank, world, port, q, mode="ddp", backend="gloo"):
         opt.step()
         opt.zero_grad(set_to_none=True)
         losses.append(float(out.loss.detach()))
+    if tl is not None:
+        summ = tl.summary()
+        assert summ is not None and summ["steps"] == 2 and summ["buckets_per_step"] >= 2, summ
+        assert summ["bucket_order"] == list(range(summ["buckets_per_step"])) and summ["comm_exposed_ms"] >= 0.0, summ
     psig = torch.stack([p.detach().float().sum() for p in model.parameters() if p.requires_grad]).cpu()
     if mode != "ddp":  # also ship the parameters themselves for the cross-mode comparison
         flat = torch.cat([p.detach().float().flatten() for p in model.parameters() if p.requires_grad]).cpu()

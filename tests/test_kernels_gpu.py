@@ -285,6 +285,37 @@ def test_gemm_streamk_tail(layout, M, N, K):
         assert rel_l2(yb, ref + bias.float() + res.float()) < 4e-3
 
 
+@pytest.mark.parametrize("layout,M,N,K", [("fwd", 8192, 8192, 512), ("fwd", 8448, 8448, 256), ("dgrad", 8192, 8192, 512),
+                                          ("wgrad", 8192, 8448, 2048)])
+def test_gemm_persistent_xcd_synchronised_walk(layout, M, N, K):
+    """Opt-in variant (bit 24 of `variant`, ops.GEMM_PERSIST): one block per CU walks its XCD's tiles, the 32 blocks of an XCD start
+    every tile together.  Same tiles, same arithmetic: results must be BIT-IDENTICAL to the one-tile-per-block launch (1089 tiles:
+    a tile count that is not a multiple of 8, so the XCDs own different numbers of tiles), and the counter page must be left at
+    zero (a second launch behaves the same)."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    rn = lambda *s, scale=1.0: (torch.randn(*s, device=DEV, generator=g) * scale).to(BF)
+    if layout == "fwd":
+        a, b = rn(M, K), rn(N, K, scale=0.05)
+        fn = lambda: ops.linear_fwd(a, b)
+    elif layout == "dgrad":
+        a, b = rn(M, K), rn(K, N, scale=0.05)
+        fn = lambda: ops.linear_dgrad(a, b)
+    else:
+        a, b = rn(K, M), rn(K, N)
+        fn = lambda: ops.linear_wgrad(a, b)
+    y0 = fn()
+    ops.GEMM_PERSIST = True
+    try:
+        y1 = fn()
+        y2 = fn()
+    finally:
+        ops.GEMM_PERSIST = False
+    assert torch.equal(y1, y0) and torch.equal(y2, y0)
+    ws = ops._streamk_workspace(a.device)
+    assert int(ws[:1024].view(torch.int32).abs().sum()) == 0
+
+
 def test_gemm_streamk_hint_only_where_it_pays():
     from dreamllm_amd import _lib
     T, d, F_ = 32768, 4096, 11008
