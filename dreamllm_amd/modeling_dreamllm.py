@@ -30,6 +30,7 @@ from transformers import PreTrainedModel
 from transformers.utils import ModelOutput
 
 from . import ops
+from . import torch_ops  # noqa: F401  (registers torch.ops.dreamllm.*)
 from .configuration_dreamllm import DreamLLMConfig
 from .tokenization_dreamllm import (
     DEFAULT_BOS_TOKEN,
@@ -56,6 +57,8 @@ class DreamLLMRMSNorm(nn.Module):
         self.variance_epsilon = eps
 
     def forward(self, hidden_states):
+        if torch.compiler.is_compiling() and not torch.is_grad_enabled():   # torch.compile(model): registered op, no graph break
+            return torch.ops.dreamllm.rmsnorm(hidden_states, self.weight, float(self.variance_epsilon))
         return ops.rmsnorm(hidden_states, self.weight, self.variance_epsilon)
 
 
@@ -473,6 +476,24 @@ class DreamLLMDecoderLayer(nn.Module):
         if output_attentions:
             raise ValueError("output_attentions is not available on the flash-attention path (modeling_dreamllm.py:934-936)")
         a = self.self_attn
+        if torch.compiler.is_compiling() and not torch.is_grad_enabled() and past_key_value is None:
+            # torch.compile(model), inference without a cache: ONE registered op per layer (torch_ops.decoder_layer), no graph break
+            B, S, _ = hidden_states.shape
+            # (the model passes the tables it built once for the whole forward: inside a traced graph the per-device cache of
+            # `RotaryEmbedding.tables` is not visible, and every layer would re-trace the sinusoid)
+            cos, sin = kwargs.get("rope_tables") or a.rotary_emb.tables(S, hidden_states.device)
+            seqlens, seqstart = kwargs.get("seqlens", None), kwargs.get("seqstart", None)
+            if seqlens is None and seqstart is None and attention_mask is not None:
+                seqstart, seqlens = _mask_to_spans(attention_mask)   # (reads a flag back: Dynamo breaks the graph here, once)
+            pos = position_ids.expand(B, S).contiguous().view(-1).long() if position_ids is not None else None
+            args = (hidden_states, self.input_layernorm.weight, a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.o_proj.weight,
+                    self.post_attention_layernorm.weight, self.mlp.gate_proj.weight, self.mlp.up_proj.weight,
+                    self.mlp.down_proj.weight, cos, sin, pos, seqlens, seqstart, a.num_heads, a.num_key_value_heads,
+                    float(self.input_layernorm.variance_epsilon))
+            if use_cache:
+                y, k, v = torch.ops.dreamllm.decoder_layer_kv(*args)
+                return (y, (k.transpose(1, 2), v.transpose(1, 2)))
+            return (torch.ops.dreamllm.decoder_layer(*args),)
         if hidden_states.is_cuda and getattr(a.config, "pack_projection_weights", True):
             # cheap per-forward check (five pointer reads): `.to(dtype/device)`, `.half()` or a re-assigned parameter drop the
             # packing; re-pack then instead of silently falling back to five GEMMs (0.4 GB of copies per 7B layer, once)
@@ -700,6 +721,8 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
         self.embed_tokens = value
 
     def embed(self, input_ids):
+        if torch.compiler.is_compiling() and not torch.is_grad_enabled():
+            return torch.ops.dreamllm.embedding(self.embed_tokens.weight, input_ids)
         return ops.embedding(self.embed_tokens.weight, input_ids)
 
     def _forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
@@ -751,13 +774,16 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
         all_hidden_states = () if output_hidden_states else None
         next_decoder_cache = () if use_cache else None
         additional_log_info = {}
+        extra = {}
+        if torch.compiler.is_compiling() and not torch.is_grad_enabled() and past_key_values is None and len(self.layers) > 0:
+            extra["rope_tables"] = self.layers[0].self_attn.rotary_emb.tables(seq_length, hidden_states.device)
         for idx, decoder_layer in enumerate(self.layers):
             if output_hidden_states:
                 all_hidden_states += (hidden_states,)
             past_key_value = past_key_values[idx] if past_key_values is not None else None
             layer_outputs = decoder_layer(hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                                           past_key_value=past_key_value, use_cache=use_cache, seqlens=seqlens,
-                                          seqstart=seqstart)
+                                          seqstart=seqstart, **extra)
             hidden_states = layer_outputs[0]
             if use_cache:
                 next_decoder_cache += (layer_outputs[1],)
@@ -995,6 +1021,8 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
             else:
                 lm_loss, logits = ops.lm_head_ce(hidden_states.reshape(B * S, H), self.lm_head.weight, shift, return_logits=True)
                 logits = logits.view(B, S, -1)
+        elif torch.compiler.is_compiling() and not torch.is_grad_enabled():
+            logits = torch.ops.dreamllm.linear(hidden_states, self.lm_head.weight, None, True)
         else:
             logits = ops.linear(hidden_states, self.lm_head.weight, out_fp32=True)
 

@@ -300,9 +300,34 @@ with torch.no_grad():
 assert torch.equal(out, ref), (out - ref).abs().max()
 print("COMPILE_OK")
 """
+    code_registered = """
+import torch
+from dreamllm_amd.factory import TINY, build_dreamllm
+lm = build_dreamllm(TINY, device="cuda", dtype=torch.bfloat16, with_clip=False, with_sd=False).eval()
+ids = torch.randint(3, 30000, (2, 40), device="cuda")
+with torch.no_grad():
+    ref = lm(input_ids=ids, return_dict=True)
+    ex = torch._dynamo.explain(lm)(input_ids=ids, return_dict=True)
+assert ex.graph_count == 1 and ex.graph_break_count == 0, ex.break_reasons
+names = [str(n.target) for g in ex.graphs for n in g.graph.nodes if n.op == "call_function"]
+assert names.count("dreamllm.decoder_layer_kv") == len(lm.model.layers) and "dreamllm.linear" in names, names
+torch._dynamo.reset()
+clm = torch.compile(lm, backend="eager")      # NO make_dynamo_opaque(): the registered torch.ops.dreamllm.* carry the forward
+with torch.no_grad():
+    out = clm(input_ids=ids, return_dict=True)
+assert torch.equal(out.logits, ref.logits), (out.logits - ref.logits).abs().max()
+for (k0, v0), (k1, v1) in zip(ref.past_key_values, out.past_key_values):
+    assert torch.equal(k0, k1) and torch.equal(v0, v1)
+print("REGISTERED_OK")
+"""
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                        cwd=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
     assert "COMPILE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    # torch.library registration (dreamllm_amd/torch_ops.py): the text forward is ONE Dynamo graph of torch.ops.dreamllm.* nodes and
+    # gives bit-identical logits and KV cache to eager execution on the HIP kernels
+    r = subprocess.run([sys.executable, "-c", code_registered], capture_output=True, text=True, timeout=600,
+                       cwd=__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    assert "REGISTERED_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
 class _FakeXLHead(nn.Module):
