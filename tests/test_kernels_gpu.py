@@ -325,7 +325,7 @@ def test_gemm_streamk_hint_only_where_it_pays():
     assert h(T, F_, d, 0, 1) == 0                                      # down dgrad: remainder 128 but K = 4096: the half round is 50 us
     assert h(T, d, d, 0, 0) == 0 and h(T, 2 * F_, d, 0, 0) == 0        # whole rounds: nothing to gain
     assert h(3 * d, d, T, 1, 1) == 0 and h(256, 256, 4096, 0, 0) == 0
-    assert _lib.call("dllm_gemm_streamk_ws_bytes") == 2 * 256 * 256 * 256 * 4
+    assert _lib.call("dllm_gemm_streamk_ws_bytes") == (2 * 256 * 256 * 256 + 1024) * 4   # slabs + the 4 KiB counter page
 
 
 def test_gemm_rejects_bad_shapes():
