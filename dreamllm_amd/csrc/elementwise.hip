@@ -41,7 +41,20 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ x, const f
 // ------------------------------------------------------------------ SwiGLU / GEGLU
 // MODE 0: out = silu(a) * b   (DreamLLMMLP, modeling_dreamllm.py:237)     a = gate, b = up
 // MODE 1: out = b_ * gelu(a)  with a = gate half, b = value half (diffusers GEGLU: hidden, gate = chunk(2); hidden*gelu(gate))
-template <int MODE>
+// NT: non-temporal loads / stores (bit 8 of the ABI's `mode`): the operands are [T, F] streams of 0.7 GB each at the LLM shape,
+// read or written exactly once by this kernel
+template <bool NT>
+__device__ __forceinline__ bf16x8 ldv(const bf16* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+    else return ld_bf16x8(p);
+}
+template <bool NT>
+__device__ __forceinline__ void stv(bf16* p, bf16x8 v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<bf16x8*>(p));
+    else st_bf16x8(p, v);
+}
+
+template <int MODE, bool NT = false>
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b,
                                                       bf16* __restrict__ out, int64_t M, int F, int64_t lda, int64_t ldb,
                                                       int64_t ldo) {
@@ -50,17 +63,17 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const bf16* __restrict__ a
     for (int64_t r = blockIdx.x; r < M; r += gridDim.x)
     for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
         const int c = v * 8;
-        const bf16x8 av = ld_bf16x8(a + r * lda + c), bv = ld_bf16x8(b + r * ldb + c);
+        const bf16x8 av = ldv<NT>(a + r * lda + c), bv = ldv<NT>(b + r * ldb + c);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float x = (float)av[e], y = (float)bv[e];
             o[e] = (bf16)((MODE == 0 ? silu_f(x) : gelu_erf_f(x)) * y);
         }
-        st_bf16x8(out + r * ldo + c, o);
+        stv<NT>(out + r * ldo + c, o);
     }
 }
-template <int MODE>
+template <int MODE, bool NT = false>
 __global__ __launch_bounds__(256) void glu_bwd_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ a,
                                                       const bf16* __restrict__ b, bf16* __restrict__ da, bf16* __restrict__ db,
                                                       bf16* __restrict__ act_out, int64_t M, int F, int64_t ldd, int64_t lda,
@@ -69,7 +82,7 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const bf16* __restrict__ d
     for (int64_t r = blockIdx.x; r < M; r += gridDim.x)
     for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
         const int c = v * 8;
-        const bf16x8 dv = ld_bf16x8(dout + r * ldd + c), av = ld_bf16x8(a + r * lda + c), bv = ld_bf16x8(b + r * ldb + c);
+        const bf16x8 dv = ldv<NT>(dout + r * ldd + c), av = ldv<NT>(a + r * lda + c), bv = ldv<NT>(b + r * ldb + c);
         bf16x8 oa, ob, oc;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -89,9 +102,9 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const bf16* __restrict__ d
             // glu_fwd_kernel (same silu_f / gelu_erf_f expression, one rounding)
             oc[e] = (bf16)((MODE == 0 ? silu_f(x) : act) * y);
         }
-        st_bf16x8(da + r * ldda + c, oa);
-        st_bf16x8(db + r * lddb + c, ob);
-        if (act_out != nullptr) st_bf16x8(act_out + r * ldact + c, oc);
+        stv<NT>(da + r * ldda + c, oa);
+        stv<NT>(db + r * lddb + c, ob);
+        if (act_out != nullptr) stv<NT>(act_out + r * ldact + c, oc);
     }
 }
 
@@ -288,6 +301,43 @@ __global__ __launch_bounds__(256) void adamw_kernel(PT* __restrict__ p, const PT
         p[i] = (PT)pf;
         m[i] = (ST)mf;
         v[i] = (ST)vf;
+    }
+}
+
+// bf16 parameters / gradients / moments, 16-byte aligned, n % 8 == 0 (every weight matrix): 8 elements per thread per access,
+// all four streams requested before the arithmetic, non-temporal (each array is touched once per step: 14 B / parameter,
+// 94.6 GB for the 7B model -- nothing of it is worth a cache line).  Same arithmetic, element for element, as adamw_kernel.
+__global__ __launch_bounds__(256) void adamw_vec8_kernel(bf16* __restrict__ p, const bf16* __restrict__ g, bf16* __restrict__ m,
+                                                         bf16* __restrict__ v, int64_t n8, float lr, float b1, float b2, float eps,
+                                                         float wd, float bc1, float bc2, float gscale,
+                                                         const float* __restrict__ gscale_dev) {
+    if (gscale_dev != nullptr) gscale *= gscale_dev[0];
+    const float decay = 1.f - lr * wd;
+    bf16x8* pv = reinterpret_cast<bf16x8*>(p);
+    const bf16x8* gv = reinterpret_cast<const bf16x8*>(g);
+    bf16x8* mv = reinterpret_cast<bf16x8*>(m);
+    bf16x8* vv = reinterpret_cast<bf16x8*>(v);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        bf16x8 P = __builtin_nontemporal_load(pv + i);
+        const bf16x8 G = __builtin_nontemporal_load(gv + i);
+        bf16x8 M = __builtin_nontemporal_load(mv + i), V = __builtin_nontemporal_load(vv + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float pf = (float)P[e];
+            const float gf = (float)G[e] * gscale;
+            float mf = (float)M[e], vf = (float)V[e];
+            pf *= decay;
+            mf = b1 * mf + (1.f - b1) * gf;
+            vf = b2 * vf + (1.f - b2) * gf * gf;
+            const float denom = sqrtf(vf) / sqrtf(bc2) + eps;
+            pf -= (lr / bc1) * mf / denom;
+            P[e] = (bf16)pf;
+            M[e] = (bf16)mf;
+            V[e] = (bf16)vf;
+        }
+        __builtin_nontemporal_store(P, pv + i);
+        __builtin_nontemporal_store(M, mv + i);
+        __builtin_nontemporal_store(V, vv + i);
     }
 }
 
@@ -500,7 +550,10 @@ int dllm_glu_fwd(const void* a, const void* b, void* out, int64_t M, int F, int6
     if (M == 0) return DLLM_OK;
     const unsigned g = (unsigned)(M < (1 << 20) ? M : (1 << 20));
     const int vpr = F / 8, nthr = vpr >= 256 ? 256 : ((vpr + 63) / 64) * 64;  // a row's vectors on 64..256 threads
-    if (mode == 0)
+    if (mode == 0x100)
+        hipLaunchKernelGGL((glu_fwd_kernel<0, true>), dim3(g), dim3(nthr), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b,
+                           (bf16*)out, M, F, lda, ldb, ldo);
+    else if (mode == 0)
         hipLaunchKernelGGL(glu_fwd_kernel<0>, dim3(g), dim3(nthr), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b,
                            (bf16*)out, M, F, lda, ldb, ldo);
     else
@@ -515,7 +568,10 @@ int dllm_glu_bwd(const void* dout, const void* a, const void* b, void* da, void*
     if (M == 0) return DLLM_OK;
     const unsigned g = (unsigned)(M < (1 << 20) ? M : (1 << 20));
     const int vpr = F / 8, nthr = vpr >= 256 ? 256 : ((vpr + 63) / 64) * 64;
-    if (mode == 0)
+    if (mode == 0x100)
+        hipLaunchKernelGGL((glu_bwd_kernel<0, true>), dim3(g), dim3(nthr), 0, (hipStream_t)stream, (const bf16*)dout, (const bf16*)a,
+                           (const bf16*)b, (bf16*)da, (bf16*)db, (bf16*)act_out, M, F, ldd, lda, ldb, ldda, lddb, ldact);
+    else if (mode == 0)
         hipLaunchKernelGGL(glu_bwd_kernel<0>, dim3(g), dim3(nthr), 0, (hipStream_t)stream, (const bf16*)dout, (const bf16*)a,
                            (const bf16*)b, (bf16*)da, (bf16*)db, (bf16*)act_out, M, F, ldd, lda, ldb, ldda, lddb, ldact);
     else
@@ -577,7 +633,12 @@ int dllm_adamw(void* p, const void* g, void* m, void* v, int64_t n, int param_dt
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     const int gsz = grid_for(n);
     hipStream_t s = (hipStream_t)stream;
-    if (param_dtype == DLLM_BF16 && state_dtype == DLLM_BF16)
+    const bool vec8 = (n & 7) == 0 && ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                                        reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    if (param_dtype == DLLM_BF16 && state_dtype == DLLM_BF16 && vec8)
+        hipLaunchKernelGGL(adamw_vec8_kernel, dim3(grid_for(n / 8)), dim3(256), 0, s, (bf16*)p, (const bf16*)g, (bf16*)m, (bf16*)v,
+                           n / 8, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, grad_scale_dev);
+    else if (param_dtype == DLLM_BF16 && state_dtype == DLLM_BF16)
         hipLaunchKernelGGL((adamw_kernel<bf16, bf16>), dim3(gsz), dim3(256), 0, s, (bf16*)p, (const bf16*)g, (bf16*)m, (bf16*)v,
                            n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, grad_scale_dev);
     else if (param_dtype == DLLM_BF16 && state_dtype == DLLM_F32)

@@ -434,6 +434,15 @@ def rope_(x, cos, sin, pos=None, backward=False):
     return x
 
 
+# SwiGLU forward / backward with non-temporal loads and stores (bit 8 of the ABI's `mode`) once the operands are far larger than the
+# caches (the LLM's [T, F] streams): measured per call in tools/elementwise_ab.py; off = the plain kernels.
+GLU_NT_MIN_BYTES = int(os.environ.get("DREAMLLM_GLU_NT_MIN_BYTES", str(1 << 62)))
+
+
+def _glu_mode(mode, M, F):
+    return (mode | 0x100) if (mode == 0 and 2 * M * F >= GLU_NT_MIN_BYTES) else mode
+
+
 def glu_fwd(a, b, mode):
     """mode 0: silu(a)*b (SwiGLU), mode 1: gelu(a)*b (GEGLU).  a, b: [..., F] views with unit inner stride."""
     _need_gpu(a, b)
@@ -442,7 +451,7 @@ def glu_fwd(a, b, mode):
     a2, b2 = a.reshape(-1, F), b.reshape(-1, F)
     M = a2.shape[0]
     out = torch.empty(M, F, dtype=a.dtype, device=a.device)
-    check("dllm_glu_fwd", _p(a2), _p(b2), _p(out), M, F, a2.stride(0), b2.stride(0), F, mode, _stream())
+    check("dllm_glu_fwd", _p(a2), _p(b2), _p(out), M, F, a2.stride(0), b2.stride(0), F, _glu_mode(mode, M, F), _stream())
     return out.view(*a.shape[:-1], F)
 
 
@@ -458,7 +467,7 @@ def glu_bwd(dout, a, b, mode, da=None, db=None, act_out=None):
         da = torch.empty(M, F, dtype=a.dtype, device=a.device)
         db = torch.empty(M, F, dtype=a.dtype, device=a.device)
     check("dllm_glu_bwd", _p(d2), _p(a2), _p(b2), _p(da), _p(db), _p(act_out), M, F, d2.stride(0), a2.stride(0), b2.stride(0),
-          da.stride(0), db.stride(0), act_out.stride(0) if act_out is not None else 0, mode, _stream())
+          da.stride(0), db.stride(0), act_out.stride(0) if act_out is not None else 0, _glu_mode(mode, M, F), _stream())
     return da, db
 
 

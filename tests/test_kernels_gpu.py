@@ -540,8 +540,29 @@ def test_adamw_matches_torch():
     pb = p0.to(BF).to(DEV)
     mb, vb = torch.zeros(n, dtype=BF, device=DEV), torch.zeros(n, dtype=BF, device=DEV)
     ops.adamw_(pb, g.to(BF).to(DEV), mb, vb, 1e-2, 0.9, 0.98, 1e-8, 0.1, 1)
-    ref = torch.optim.AdamW([p0.to(BF).clone().requires_grad_(True)], lr=1e-2)
     assert torch.isfinite(pb.float()).all()
+    # the 8-wide non-temporal kernel (aligned, n % 8 == 0: every weight matrix) against the scalar kernel (same buffers shifted by
+    # one element => unaligned => scalar path): bit-identical parameters and moments over three steps, with a device-side clip factor
+    n8 = 8 * 4099
+    pa, ga = torch.randn(n8 + 8).to(BF).to(DEV), (torch.randn(n8 + 8) * 0.1).to(BF).to(DEV)
+    coef = torch.tensor([0.37], device=DEV)
+    bufs = {}
+    for tag, off in (("vec", 8), ("scalar", 1)):
+        mk = lambda src: torch.cat([src.new_zeros(off), src[8:8 + n8]])[off:]       # same values at a different alignment
+        P, G = mk(pa).clone(), mk(ga).clone()
+        M, V = torch.zeros(n8 + off, dtype=BF, device=DEV)[off:], torch.zeros(n8 + off, dtype=BF, device=DEV)[off:]
+        assert (P.data_ptr() % 16 == 0) == (tag == "vec")
+        for step in range(1, 4):
+            ops.adamw_(P, G, M, V, 1e-2, 0.9, 0.98, 1e-8, 0.1, step, 1.0, coef)
+        bufs[tag] = (P.clone(), M.clone(), V.clone())
+    for a, b in zip(bufs["vec"], bufs["scalar"]):
+        assert torch.equal(a, b)
+    pt = pa[8:8 + n8].float().cpu().clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pt], lr=1e-2, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.1)
+    for step in range(1, 4):
+        pt.grad = ga[8:8 + n8].float().cpu() * 0.37
+        opt.step()
+    assert rel_l2(bufs["vec"][0], pt) < 6e-3          # bf16 parameters and moments: three roundings per step
 
 
 # ----------------------------------------------------------------------------- autograd wrappers
