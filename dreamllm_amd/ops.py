@@ -435,8 +435,9 @@ def rope_(x, cos, sin, pos=None, backward=False):
 
 
 # SwiGLU forward / backward with non-temporal loads and stores (bit 8 of the ABI's `mode`) once the operands are far larger than the
-# caches (the LLM's [T, F] streams): measured per call in tools/elementwise_ab.py; off = the plain kernels.
-GLU_NT_MIN_BYTES = int(os.environ.get("DREAMLLM_GLU_NT_MIN_BYTES", str(1 << 62)))
+# caches (the LLM's [T, F] streams; default: operands of at least 64 MiB); tools/elementwise_ab.py is the A/B.
+# Measured at [32768, 11008] (profiles/r03_elementwise_ab.log): forward 5.55 -> 5.92 TB/s, backward 5.74 -> 6.08 TB/s.
+GLU_NT_MIN_BYTES = int(os.environ.get("DREAMLLM_GLU_NT_MIN_BYTES", str(64 << 20)))
 
 
 def _glu_mode(mode, M, F):

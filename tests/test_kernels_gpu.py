@@ -548,8 +548,8 @@ def test_adamw_matches_torch():
     coef = torch.tensor([0.37], device=DEV)
     bufs = {}
     for tag, off in (("vec", 8), ("scalar", 1)):
-        mk = lambda src: torch.cat([src.new_zeros(off), src[8:8 + n8]])[off:]       # same values at a different alignment
-        P, G = mk(pa).clone(), mk(ga).clone()
+        mk = lambda src: torch.cat([src.new_zeros(off), src[8:8 + n8]])[off:]       # same values at a different alignment (a VIEW)
+        P, G = mk(pa), mk(ga)
         M, V = torch.zeros(n8 + off, dtype=BF, device=DEV)[off:], torch.zeros(n8 + off, dtype=BF, device=DEV)[off:]
         assert (P.data_ptr() % 16 == 0) == (tag == "vec")
         for step in range(1, 4):

@@ -46,7 +46,7 @@ for name, fn, nbytes in cases:
     a, b = statistics.median(res[True]), statistics.median(res[False])
     print(f"{name:32s} nt {a * 1e3:7.1f} us = {nbytes / a / 1e9:6.2f} TB/s | plain {b * 1e3:7.1f} us = {nbytes / b / 1e9:6.2f} TB/s | "
           f"{100 * (b / a - 1):+.1f} %  identical={torch.equal(outs[True], outs[False])}", flush=True)
-ops.GLU_NT_MIN_BYTES = 1 << 62
+ops.GLU_NT_MIN_BYTES = 64 << 20
 # AdamW: the largest parameter tensor of the 7B model (packed gate|up: 22016 x 4096) -- 8-wide non-temporal kernel vs the scalar one
 n = 22016 * 4096
 for off, tag in ((0, "vec8 nt"), (1, "scalar")):
