@@ -267,7 +267,10 @@ def main():
         torch.cuda.synchronize()
         ops.GEMM_PROFILE = []
         if timeline is not None:
+            per_step_buckets = max(1, len(timeline.records) // max(1, a.warmup + 1))
             timeline.reset()
+            timeline.prealloc(2 * per_step_buckets * a.steps + 64)   # event creation stays outside the timed region
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.steps):
             out = step()
