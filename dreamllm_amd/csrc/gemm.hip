@@ -933,13 +933,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ---- implicit-GEMM gather through LDS-DMA (3x3 / 1x1 NHWC convolutions on the pipelined kernel) ----------------------
 // global_load_lds takes a per-lane source address, so the im2col gather costs nothing extra: lane (row r of the DMA group,
 // 16-byte chunk c) reads channels ci..ci+7 of tap (kh, kw) of output pixel m0 + r.  Taps that fall outside the image (and
-// rows past M) read a 16-byte zero page instead.  Requires C % 64 == 0 (a 64-deep K tile never straddles two taps), plain
-// geometry (no fused upsample / transposed mode): every SD-2.1 / SDXL UNet and VAE conv except conv_in.
+// rows past M) read a 16-byte zero page instead.  Requires C % 64 == 0 (a 64-deep K tile never straddles two taps): every
+// SD-2.1 / SDXL UNet and VAE conv except conv_in.  Round 3: the fused nearest-2x upsample and the transposed stride-2 gather
+// (physical pixel = logical >> 1, parity mask for the zero-stuffed grid) ride on the same per-lane source address.
 __device__ __attribute__((aligned(16))) bf16 g_zero_page[8];
 
 struct ConvDma {
-    int64_t pix_off[4];   // element offset of (img, oh*stride - pad, ow*stride - pad, 0) for the lane's row in each A group
-    unsigned tapmask[4];  // bit (kh*KW + kw): that tap reads inside the image
+    int64_t pix_off[4];   // element offset of (img, oh*stride - pad, ow*stride - pad, 0) for the lane's row in each A group;
+                          // shift modes (fused nearest-2x upsample / transposed stride-2 gather): offset of the image only
+    unsigned tapmask[4];  // bit (kh*KW + kw): that tap reads inside the image (shift modes: and, for `even_only`, an even position)
+    unsigned org[4];      // shift modes: (ih0 + 2) << 16 | (iw0 + 2), the row's LOGICAL top-left input coordinate (>= -1), biased
 };
 __device__ __forceinline__ void conv_dma_init(ConvDma& d, const ConvGeom& g, int64_t m0, int64_t M, int wave, int lane) {
 #pragma unroll
@@ -947,18 +950,27 @@ __device__ __forceinline__ void conv_dma_init(ConvDma& d, const ConvGeom& g, int
         const int64_t m = m0 + (wave * 4 + q) * 8 + (lane >> 3);
         d.pix_off[q] = 0;
         d.tapmask[q] = 0;
+        d.org[q] = 0;
         if (m < M) {
             const int64_t hw = (int64_t)g.OH * g.OW;
             const int64_t img = m / hw;
             const int rem = (int)(m - img * hw);
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
             const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
-            d.pix_off[q] = img * (int64_t)g.H * g.W * g.C + ((int64_t)ih0 * g.W + iw0) * g.C;
+            const bool shift = (g.up_shift | g.even_only) != 0;
+            d.pix_off[q] = img * (int64_t)g.H * g.W * g.C + (shift ? (int64_t)0 : ((int64_t)ih0 * g.W + iw0) * g.C);
+            d.org[q] = ((unsigned)(ih0 + 2) << 16) | (unsigned)(iw0 + 2);
             unsigned mk = 0;
             for (int kh = 0; kh < g.KH; ++kh)
                 for (int kw = 0; kw < g.KW; ++kw) {
-                    const int ih = ih0 + kh, iw = iw0 + kw;
-                    if (ih >= 0 && ih < g.H && iw >= 0 && iw < g.W) mk |= 1u << (kh * g.KW + kw);
+                    int ih = ih0 + kh, iw = iw0 + kw;
+                    bool ok = ih >= 0 && iw >= 0;
+                    if (shift) {   // logical grid = 2x the physical one: nearest-2x upsample, or the zero-stuffed grid of a stride-2 dgrad
+                        if (g.even_only) ok = ok && ((ih & 1) == 0) && ((iw & 1) == 0);
+                        ih >>= 1;
+                        iw >>= 1;
+                    }
+                    if (ok && ih < g.H && iw < g.W) mk |= 1u << (kh * g.KW + kw);
                 }
             d.tapmask[q] = mk;
         }
@@ -972,7 +984,13 @@ __device__ __forceinline__ void glds_conv_one(const bf16* x, const ConvGeom& g, 
     const int c = (lane & 7) ^ ((r >> 1) & 7);
     const int kh = tap / g.KW, kw = tap - kh * g.KW;
     const bool ok = (d.tapmask[q] >> tap) & 1u;
-    const bf16* src = ok ? x + d.pix_off[q] + (int64_t)((kh * g.W + kw) * g.C + ci0 + c * 8) : g_zero_page;
+    const bf16* src;
+    if (g.up_shift | g.even_only) {   // (uniform) physical pixel = logical >> 1
+        const int ih = ((int)(d.org[q] >> 16) - 2 + kh) >> 1, iw = ((int)(d.org[q] & 0xffffu) - 2 + kw) >> 1;
+        src = ok ? x + d.pix_off[q] + (int64_t)((ih * g.W + iw) * g.C + ci0 + c * 8) : g_zero_page;
+    } else {
+        src = ok ? x + d.pix_off[q] + (int64_t)((kh * g.W + kw) * g.C + ci0 + c * 8) : g_zero_page;
+    }
     GLDS16(src, tile + grp * 1024);
 }
 
@@ -1369,7 +1387,7 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);
     bool glds_ok = V.use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K);
     if (AL == A_CONV)  // LDS-DMA gather: plain geometry, a K tile inside one tap, pipelined kernel only
-        glds_ok = glds_ok && V.glds_pipe && (P.cv.C % BK) == 0 && !P.cv.up_shift && !P.cv.even_only && BL == B_K;
+        glds_ok = glds_ok && V.glds_pipe && (P.cv.C % BK) == 0 && BL == B_K;
     const double e256 = tile_eff(P.M, P.N, 256, glds_ok ? 1.15 : 1.0), e128 = tile_eff(P.M, P.N, 128, 0.85);
     const bool pick256 = e256 >= e128;
     if (P.splitk > 1) return launch_gemm_t<AL, BL, 128>(P, stream);

@@ -901,11 +901,13 @@ LM_HEAD_CE_CHUNK_ROWS = int(os.environ.get("DREAMLLM_CE_CHUNK_ROWS", "4096"))  #
 
 
 def _pad_vocab(weight):
-    """vocabulary not a multiple of 8 (DreamLLM-SDXL: 32009): the GEMMs of the backward contract over / produce the
-    vocabulary axis and need 16-byte rows, so the unit runs on a zero-padded weight; the CE kernel still sees V columns (row
-    pitch Vp), so the pad columns enter neither the softmax nor the gradient."""
+    """The GEMMs of the backward contract over / produce the vocabulary axis: they need 16-byte rows (V % 8 == 0; DreamLLM-SDXL has
+    32009) and run on the pipelined LDS-DMA kernel only when the contraction length is a multiple of 64 (32008 = 64 * 500 + 8: the
+    dHidden GEMM of every chunk otherwise falls to the register-staged kernel, 0.87 instead of 1.25 PF).  So the unit runs on a
+    weight zero-padded to a multiple of 64 rows (one 262 MB copy per call, 0.1 ms); the CE kernel still sees V columns (row pitch
+    Vp), so the pad columns enter neither the softmax nor the gradient."""
     V = weight.shape[0]
-    Vp = (V + 7) // 8 * 8
+    Vp = (V + 63) // 64 * 64
     if Vp == V:
         return weight
     wp = torch.zeros(Vp, weight.shape[1], dtype=weight.dtype, device=weight.device)
