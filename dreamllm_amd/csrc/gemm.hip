@@ -29,6 +29,7 @@ namespace {
 
 constexpr int BK = 64;
 constexpr int A_K = 0, A_M = 1, A_CONV = 2;
+constexpr int A_CONVS = 3;  // pipelined kernel only: conv gather with "shift" addressing (fused nearest-2x upsample / transposed stride-2)
 constexpr int B_K = 0, B_N = 1;
 
 constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
@@ -944,6 +945,7 @@ struct ConvDma {
     unsigned tapmask[4];  // bit (kh*KW + kw): that tap reads inside the image (shift modes: and, for `even_only`, an even position)
     unsigned org[4];      // shift modes: (ih0 + 2) << 16 | (iw0 + 2), the row's LOGICAL top-left input coordinate (>= -1), biased
 };
+template <bool SHIFT>
 __device__ __forceinline__ void conv_dma_init(ConvDma& d, const ConvGeom& g, int64_t m0, int64_t M, int wave, int lane) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -957,9 +959,9 @@ __device__ __forceinline__ void conv_dma_init(ConvDma& d, const ConvGeom& g, int
             const int rem = (int)(m - img * hw);
             const int oh = rem / g.OW, ow = rem - oh * g.OW;
             const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
-            const bool shift = (g.up_shift | g.even_only) != 0;
+            constexpr bool shift = SHIFT;   // a separate instantiation: the plain gather keeps its round-2 instruction stream
             d.pix_off[q] = img * (int64_t)g.H * g.W * g.C + (shift ? (int64_t)0 : ((int64_t)ih0 * g.W + iw0) * g.C);
-            d.org[q] = ((unsigned)(ih0 + 2) << 16) | (unsigned)(iw0 + 2);
+            if constexpr (SHIFT) d.org[q] = ((unsigned)(ih0 + 2) << 16) | (unsigned)(iw0 + 2);
             unsigned mk = 0;
             for (int kh = 0; kh < g.KH; ++kh)
                 for (int kw = 0; kw < g.KW; ++kw) {
@@ -977,6 +979,7 @@ __device__ __forceinline__ void conv_dma_init(ConvDma& d, const ConvGeom& g, int
     }
 }
 // q-th A group of the wave for the K tile that starts at channel ci0 of tap `tap` (both uniform)
+template <bool SHIFT>
 __device__ __forceinline__ void glds_conv_one(const bf16* x, const ConvGeom& g, const ConvDma& d, int tap, int ci0, char* tile,
                                               int wave, int lane, int q) {
     const int grp = wave * 4 + q;
@@ -985,7 +988,7 @@ __device__ __forceinline__ void glds_conv_one(const bf16* x, const ConvGeom& g, 
     const int kh = tap / g.KW, kw = tap - kh * g.KW;
     const bool ok = (d.tapmask[q] >> tap) & 1u;
     const bf16* src;
-    if (g.up_shift | g.even_only) {   // (uniform) physical pixel = logical >> 1
+    if constexpr (SHIFT) {   // physical pixel = logical >> 1
         const int ih = ((int)(d.org[q] >> 16) - 2 + kh) >> 1, iw = ((int)(d.org[q] & 0xffffu) - 2 + kw) >> 1;
         src = ok ? x + d.pix_off[q] + (int64_t)((ih * g.W + iw) * g.C + ci0 + c * 8) : g_zero_page;
     } else {
@@ -1019,11 +1022,12 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave / WC) * (MI * 16), wn = (wave % WC) * 64;
 
+    constexpr bool CONV = (AL == A_CONV || AL == A_CONVS), SHIFT = (AL == A_CONVS);
     ConvDma cdma;
-    if constexpr (AL == A_CONV) conv_dma_init(cdma, P.cv, m0, P.M, wave, lane);
+    if constexpr (CONV) conv_dma_init<SHIFT>(cdma, P.cv, m0, P.M, wave, lane);
     // conv: tap / first channel of the K tile being prefetched (advanced incrementally: no division inside the loop)
     int ctap = 0, cci = 0;
-    if constexpr (AL == A_CONV) {
+    if constexpr (CONV) {
         if (kt0 != 0) {
             ctap = (int)(((int64_t)kt0 * BK) / P.cv.C);
             cci = (int)(((int64_t)kt0 * BK) % P.cv.C);
@@ -1039,7 +1043,7 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
             glds_mc_tile(P.A, P.lda, m0, P.M, k0, ta, wave, lane);
         else {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) glds_conv_one(P.A, P.cv, cdma, (int)(k0 / P.cv.C), (int)(k0 % P.cv.C), ta, wave, lane, q);
+            for (int q = 0; q < 4; ++q) glds_conv_one<SHIFT>(P.A, P.cv, cdma, (int)(k0 / P.cv.C), (int)(k0 % P.cv.C), ta, wave, lane, q);
         }
         if constexpr (BN == 128) {
 #pragma unroll
@@ -1075,7 +1079,7 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
             else if constexpr (AL == A_M)
                 glds_mc_one(P.A, P.lda, m0, P.M, k0, ta, wave, lane, q);
             else
-                glds_conv_one(P.A, P.cv, cdma, ctap, cci, ta, wave, lane, q);
+                glds_conv_one<SHIFT>(P.A, P.cv, cdma, ctap, cci, ta, wave, lane, q);
         } else {
             if constexpr (BN == 128)
                 glds_kc_grp(P.B, P.ldb, n0, P.N, k0, tb, wave * NBD + (q - 4), lane);
@@ -1096,7 +1100,7 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
         const bool pf = (t + 1 < kt1) && P.dbg_noload != 1;
         const int64_t kpf = P.dbg_noload == 2 ? (int64_t)0 : (int64_t)(t + 1) * BK;
         const int nbuf = (t - kt0 + 1) & 1;
-        if constexpr (AL == A_CONV) {  // K tile t+1 starts BK channels further; wraps into the next tap at C
+        if constexpr (CONV) {  // K tile t+1 starts BK channels further; wraps into the next tap at C
             cci += BK;
             if (cci >= P.cv.C) {
                 cci -= P.cv.C;
@@ -1402,10 +1406,17 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
         }
         if (glds_ok && V.glds_pipe && n128) {
             constexpr int LDSN = 2 * (256 + 128) * BK * 2;
-            static std::atomic<uint64_t> ldsn_ok{0};
-            dllm_ensure_dyn_lds(&gemm_pipe_kernel<AL, BL, 128>, LDSN, ldsn_ok);
+            static std::atomic<uint64_t> ldsn_ok{0}, ldsn_s_ok{0};
             const int64_t tiles = cdiv64(P.M, 256) * cdiv64(P.N, 128);
             if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+            if constexpr (AL == A_CONV) {
+                if (P.cv.up_shift | P.cv.even_only) {   // shift addressing: its own instantiation (the plain gather is untouched)
+                    dllm_ensure_dyn_lds(&gemm_pipe_kernel<A_CONVS, BL, 128>, LDSN, ldsn_s_ok);
+                    hipLaunchKernelGGL((gemm_pipe_kernel<A_CONVS, BL, 128>), dim3((unsigned)tiles), dim3(512), LDSN, stream, P);
+                    return dllm_check_launch();
+                }
+            }
+            dllm_ensure_dyn_lds(&gemm_pipe_kernel<AL, BL, 128>, LDSN, ldsn_ok);
             hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL, 128>), dim3((unsigned)tiles), dim3(512), LDSN, stream, P);
             return dllm_check_launch();
         }
@@ -1415,7 +1426,12 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
             if constexpr (BL == B_K) {
                 if (glds_ok) {
                     constexpr int LDS = 2 * 2 * 256 * BK * 2;
-                    static std::atomic<uint64_t> lds_ok{0};
+                    static std::atomic<uint64_t> lds_ok{0}, lds_s_ok{0};
+                    if (P.cv.up_shift | P.cv.even_only) {
+                        dllm_ensure_dyn_lds(&gemm_pipe_kernel<A_CONVS, BL>, LDS, lds_s_ok);
+                        hipLaunchKernelGGL((gemm_pipe_kernel<A_CONVS, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);
+                        return dllm_check_launch();
+                    }
                     dllm_ensure_dyn_lds(&gemm_pipe_kernel<AL, BL>, LDS, lds_ok);
                     hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)tiles256), dim3(512), LDS, stream, P);
                     return dllm_check_launch();
