@@ -30,6 +30,7 @@ SIGNATURES = {
     "dllm_conv2d_nhwc_bf16_splitk": [c_void_p] * 6 + [c_int] * 15 + [c_int, c_void_p, c_void_p, c_int, c_void_p],
     "dllm_conv2d_nhwc_bf16": [c_void_p] * 6 + [c_int] * 15 + [c_void_p],
     "dllm_groupnorm_fwd": [c_void_p] * 8 + [c_int] * 4 + [c_float, c_int, c_void_p],
+    "dllm_groupnorm_fwd_split": [c_void_p] * 7 + [c_int] * 4 + [c_float, c_int, c_void_p],
     "dllm_groupnorm_bwd": [c_void_p] * 10 + [c_int] * 5 + [c_void_p],
     "dllm_sumpool2_nhwc": [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p],
     "dllm_cfg_ddim_step": [c_void_p] * 3 + [c_i64, c_i64] + [c_float] * 5 + [c_int, c_void_p],

@@ -220,6 +220,109 @@ __global__ __launch_bounds__(1024) void gn_small_kernel(const bf16* __restrict__
     }
 }
 
+// gn_small_kernel spread over S blocks per (image, group) (round 3).  At batch 2 the UNet's GroupNorms are 64 blocks on a 256-CU
+// chip, each a chain of ~10 dependent 4-byte load batches (15 us per launch, 61 launches per denoising step = 11 % of the step).  Here
+// S blocks take a quarter of the pixels each; their partial sums meet in a 128-byte slot of a caller-owned, zero-initialised `sync`
+// buffer: {arrival count, epoch flag, S x (sum, sum of squares)}, all accessed with agent-scope atomics (the S blocks may sit on
+// different XCDs, whose L2s are not coherent for plain accesses).  Every block publishes its sums, waits until they have completed,
+// takes a ticket; the last arriver zeroes the count and bumps the epoch, the others spin on the epoch they read before arriving.  The
+// totals are then summed in slot order by every block: deterministic, identical in all S blocks.  All NB * G * S blocks are
+// co-resident by construction (host: at most 512 blocks of 1024 threads), so the wait cannot deadlock.
+template <int S>
+__global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gamma,
+                                                              const bf16* __restrict__ beta, bf16* __restrict__ y,
+                                                              float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                              unsigned* __restrict__ sync, int HW, int C, int G, float eps, int act) {
+    __shared__ float red[32];
+    __shared__ float tot[2];
+    const int grp = blockIdx.x / S, part = blockIdx.x - grp * S;
+    const int n = grp / G, g = grp - n * G;
+    const int cpg = C / G, pp = cpg >> 1;
+    const int R = 1024 / pp;
+    const int r = threadIdx.x / pp, j = threadIdx.x - r * pp;
+    const bool live = r < R;
+    const int per = HW / S, p0 = part * per, p1 = p0 + per;
+    const int64_t base = (int64_t)n * HW * C + g * cpg + 2 * j;
+    const int64_t stride = (int64_t)R * C;
+    unsigned* slot = sync + (int64_t)grp * 32;
+    unsigned f0 = 0;
+    if (threadIdx.x == 0) {
+        f0 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epoch is read BEFORE this block arrives
+    }
+    float s1 = 0.f, s2 = 0.f;
+    if (live) {
+        const bf16* px = x + base + (int64_t)(p0 + r) * C;
+        int p = p0 + r;
+        for (; p + 3 * R < p1; p += 4 * R, px += 4 * stride) {
+            const bf16x2 v0 = *reinterpret_cast<const bf16x2*>(px), v1 = *reinterpret_cast<const bf16x2*>(px + stride);
+            const bf16x2 v2 = *reinterpret_cast<const bf16x2*>(px + 2 * stride), v3 = *reinterpret_cast<const bf16x2*>(px + 3 * stride);
+            const float a0 = (float)v0[0], b0 = (float)v0[1], a1 = (float)v1[0], b1 = (float)v1[1];
+            const float a2 = (float)v2[0], b2 = (float)v2[1], a3 = (float)v3[0], b3 = (float)v3[1];
+            s1 += (a0 + b0) + (a1 + b1) + (a2 + b2) + (a3 + b3);
+            s2 += (a0 * a0 + b0 * b0) + (a1 * a1 + b1 * b1) + (a2 * a2 + b2 * b2) + (a3 * a3 + b3 * b3);
+        }
+        for (; p < p1; p += R, px += stride) {
+            const bf16x2 v = *reinterpret_cast<const bf16x2*>(px);
+            const float a = (float)v[0], b = (float)v[1];
+            s1 += a + b;
+            s2 += a * a + b * b;
+        }
+    }
+    s1 = block_sum<16>(s1, red);
+    s2 = block_sum<16>(s2, red + 16);
+    if (threadIdx.x == 0) {
+        float* fs = reinterpret_cast<float*>(slot + 2);
+        __hip_atomic_store(fs + 2 * part, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fs + 2 * part + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // published before the ticket is taken
+        const unsigned old = __hip_atomic_fetch_add(slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)(S - 1)) {
+            __hip_atomic_store(slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(slot + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f0) __builtin_amdgcn_s_sleep(1);
+        }
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+            t1 += __hip_atomic_load(fs + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t2 += __hip_atomic_load(fs + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        tot[0] = t1;
+        tot[1] = t2;
+    }
+    __syncthreads();
+    const float cnt = (float)HW * (float)cpg;
+    const float mean = tot[0] / cnt;
+    const float rstd = rsqrtf(fmaxf(tot[1] / cnt - mean * mean, 0.f) + eps);
+    if (threadIdx.x == 0 && part == 0) {
+        mean_o[n * G + g] = mean;
+        rstd_o[n * G + g] = rstd;
+    }
+    if (live) {
+        const int c = g * cpg + 2 * j;
+        const float a0 = rstd * (float)gamma[c], a1 = rstd * (float)gamma[c + 1];
+        const float b0 = (float)beta[c] - mean * a0, b1 = (float)beta[c + 1] - mean * a1;
+        const bf16* px = x + base + (int64_t)(p0 + r) * C;
+        bf16* py = y + base + (int64_t)(p0 + r) * C;
+#pragma unroll 4
+        for (int p = p0 + r; p < p1; p += R, px += stride, py += stride) {
+            const bf16x2 v = *reinterpret_cast<const bf16x2*>(px);
+            float z0 = (float)v[0] * a0 + b0, z1 = (float)v[1] * a1 + b1;
+            if (act) {
+                z0 = silu_f(z0);
+                z1 = silu_f(z1);
+            }
+            bf16x2 o;
+            o[0] = (bf16)z0;
+            o[1] = (bf16)z1;
+            *reinterpret_cast<bf16x2*>(py) = o;
+        }
+    }
+}
+
 // dx = rstd * (dxhat - c1 - xhat * c2)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -329,6 +432,22 @@ int dllm_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void*
     const int64_t tv = (int64_t)NB * HW * (C / 8);
     int grid = (int)((tv + 255) / 256 > 8192 ? 8192 : (tv + 255) / 256);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, ab, (bf16*)y, tv, HW, C, act);
+    return dllm_check_launch();
+}
+
+// Split form of the single-launch path for tiny batches: `sync` = caller-owned int32 buffer of at least NB * G * 32 words, all zero
+// before the first use and left consistent (count zero) by every launch; one buffer per stream in flight.  Returns DLLM_ERR_SHAPE
+// when the problem is not eligible (the caller then takes dllm_groupnorm_fwd).
+int dllm_groupnorm_fwd_split(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int* sync,
+                             int NB, int HW, int C, int G, float eps, int act, void* stream) {
+    if (NB <= 0 || HW <= 0 || C <= 0 || G <= 0 || (C % G) != 0 || sync == nullptr) return DLLM_ERR_SHAPE;
+    const int cpg = C / G;
+    constexpr int S = 4;
+    if ((int64_t)NB * HW * C > ((int64_t)1 << 23) || (cpg & 1) || cpg > 512 || HW < 1024 || (HW % S) != 0 || NB * G * S > 512)
+        return DLLM_ERR_SHAPE;
+    hipLaunchKernelGGL(gn_small_split_kernel<S>, dim3(NB * G * S), dim3(1024), 0, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)gamma, (const bf16*)beta, (bf16*)y, mean, rstd, reinterpret_cast<unsigned*>(sync), HW, C, G, eps,
+                       act);
     return dllm_check_launch();
 }
 

@@ -1107,12 +1107,35 @@ class ConvFn(torch.autograd.Function):
         return dx, None, None, None, dres, dib, None, None, None
 
 
+# GroupNorm for tiny batches (the denoising loop): 4 blocks per (image, group) meeting in a persistent zero-initialised sync buffer
+# (include/dreamllm_hip.h: dllm_groupnorm_fwd_split); one buffer per (device, stream).  DREAMLLM_GN_SPLIT=0 disables it.
+GN_SPLIT = os.environ.get("DREAMLLM_GN_SPLIT", "1") != "0"
+_GN_SYNC = {}
+
+
+def _gn_sync(device):
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    b = _GN_SYNC.get(key)
+    if b is None:
+        b = _GN_SYNC[key] = torch.zeros(128 * 32, dtype=torch.int32, device=device)
+    return b
+
+
 def groupnorm_fwd(x, gamma, beta, G, eps, act):
     _need_gpu(x, gamma, beta)
     _bf16(x, gamma, beta)
     x = x if x.is_contiguous() else x.contiguous()
     N, C = x.shape[0], x.shape[-1]
     HW = x.numel() // (N * C)
+    if (GN_SPLIT and N * G <= 128 and HW >= 1024 and HW % 4 == 0 and N * HW * C <= (1 << 23) and (C // G) % 2 == 0
+            and C // G <= 512):
+        # (the sync buffer of a capturing stream is the one allocated by the warm-up calls on that stream, before capture)
+        mean = torch.empty(N, G, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(N, G, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        check("dllm_groupnorm_fwd_split", _p(x), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _p(_gn_sync(x.device)), N, HW, C, G,
+              float(eps), int(act), _stream())
+        return y, mean, rstd
     ws = _lib.lib().dllm_groupnorm_ws_floats(N, HW, C)
     if ws < 0:
         raise ValueError("groupnorm: unsupported shape")

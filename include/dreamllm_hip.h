@@ -57,6 +57,12 @@ int64_t dllm_groupnorm_ws_floats(int NB, int HW, int C);
 int dllm_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, float* ab,
                        float* part, int NB, int HW, int C, int G, float eps, int act, void* stream);
 /* input gradient only (affine frozen: modeling_plugins.py:405-407); c1,c2: fp32 [NB,G] scratch */
+/* Single-launch GroupNorm(+SiLU) spread over 4 blocks per (image, group) for tiny batches (the UNet inside the denoising loop at batch
+ * 2: 64 (image, group) pairs on 256 CUs).  `sync`: caller-owned int32[>= NB*G*32], zero before the first use, left consistent by every
+ * launch (one buffer per stream in flight).  Eligible when NB*HW*C <= 2^23, HW >= 1024, HW % 4 == 0, NB*G*4 <= 512; otherwise
+ * DLLM_ERR_SHAPE and the caller uses dllm_groupnorm_fwd.  Same results as dllm_groupnorm_fwd up to fp32 summation order. */
+int dllm_groupnorm_fwd_split(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int* sync,
+                             int NB, int HW, int C, int G, float eps, int act, void* stream);
 int dllm_groupnorm_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean, const float* rstd,
                        void* dx, float* c1, float* c2, float* part, int NB, int HW, int C, int G, int act, void* stream);
 
