@@ -1349,6 +1349,21 @@ static inline bool streamk_plan(int64_t M, int64_t N, int64_t K, int& full, int&
     return true;
 }
 
+// Small grids with a deep reduction (the UNet's 1280-channel 3x3 convs at 16 x 16: M = 4096 at batch 16 = 80 tiles of 256 x 256
+// with K = 11520 = 180 K tiles; a whole-tile launch fills 31 % of the chip, the 256 x 128 tiles 62 %): ALL tiles go through the
+// stream-K machinery (sk_full = 0): 256 blocks take tiles * nt / 256 K tiles each.
+static inline bool streamk_plan_small(int64_t M, int64_t N, int64_t K, int& tail, int& w, int& blocks) {
+    const int64_t tiles = cdiv64(M, 256) * cdiv64(N, 256);
+    const int64_t nt = K / BK;
+    if (tiles < 48 || tiles > 208 || nt < 96 || (K % BK) != 0) return false;
+    const int64_t total = tiles * nt;
+    w = (int)cdiv64(total, 256);
+    if (w < 32) return false;
+    tail = (int)tiles;
+    blocks = (int)cdiv64(total, w);
+    return true;
+}
+
 template <int AL, int BL, int T>
 int launch_gemm_t(const GemmParams& P, hipStream_t stream) {
     const int64_t tiles = cdiv64(P.M, T) * cdiv64(P.N, T);
@@ -1395,6 +1410,30 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     const double e256 = tile_eff(P.M, P.N, 256, glds_ok ? 1.15 : 1.0), e128 = tile_eff(P.M, P.N, 128, 0.85);
     const bool pick256 = e256 >= e128;
     if (P.splitk > 1) return launch_gemm_t<AL, BL, 128>(P, stream);
+    if constexpr (!(AL == A_M && BL == B_K)) {
+        int tail = 0, w = 0, blocks = 0;
+        if (P.ws != nullptr && glds_ok && V.glds_pipe && V.force_tile == 0 && !V.force_n128 && P.dbg_noload == 0 &&
+            streamk_plan_small(P.M, P.N, P.K, tail, w, blocks)) {
+            constexpr int LDS = 2 * 2 * 256 * BK * 2;
+            GemmParams Q = P;
+            Q.sk_full = 0; Q.sk_tail = tail; Q.sk_w = w;
+            static std::atomic<uint64_t> ldst_ok{0}, ldsts_ok{0};
+            bool shift = false;
+            if constexpr (AL == A_CONV) shift = (P.cv.up_shift | P.cv.even_only) != 0;
+            if constexpr (AL == A_CONV) {
+                if (shift) {
+                    dllm_ensure_dyn_lds(&gemm_pipe_tail_kernel<A_CONVS, BL>, LDS, ldsts_ok);
+                    hipLaunchKernelGGL((gemm_pipe_tail_kernel<A_CONVS, BL>), dim3((unsigned)blocks), dim3(512), LDS, stream, Q);
+                }
+            }
+            if (!shift) {
+                dllm_ensure_dyn_lds(&gemm_pipe_tail_kernel<AL, BL>, LDS, ldst_ok);
+                hipLaunchKernelGGL((gemm_pipe_tail_kernel<AL, BL>), dim3((unsigned)blocks), dim3(512), LDS, stream, Q);
+            }
+            hipLaunchKernelGGL(gemm_pipe_fixup_kernel, dim3((unsigned)tail), dim3(512), 0, stream, Q);
+            return dllm_check_launch();
+        }
+    }
     if constexpr (BL == B_K && (AL == A_K || AL == A_CONV)) {
         // narrow outputs (N = 320: 62 % of two 256-wide tiles, 83 % of three 128-wide ones): the pipelined kernel on 256 x 128 tiles
         bool n128 = V.force_n128 != 0;
@@ -1544,6 +1583,11 @@ int64_t dllm_gemm_streamk_ws_bytes(void) { return SK_WS_BYTES; }
 int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int layout_b) {
     if (M <= 0 || N <= 0 || K < BK || (K % BK) != 0) return 0;
     if (layout_a == A_M && layout_b == B_K) return 0;
+    {   // small grid, deep K (layout_a 2 = implicit-GEMM conv, K = KH*KW*C with C % 64 == 0 checked by the caller)
+        int tail, w, blocks;
+        if (streamk_plan_small(M, N, K, tail, w, blocks)) return 1;
+    }
+    if (layout_a == A_CONV) return 0;
     if (tile_eff(M, N, 256, 1.15) < tile_eff(M, N, 128, 0.85)) return 0;
     int full, tail, w, blocks;
     return streamk_plan(M, N, K, full, tail, w, blocks) ? 1 : 0;

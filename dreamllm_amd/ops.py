@@ -227,11 +227,19 @@ def _streamk_hint(M, N, K, layout_a, layout_b):
 
 def _streamk_workspace(device):
     """One workspace per (device, stream): two GEMMs in flight on different streams must not share slabs / counters.  Zero-filled
-    once: its first 4 KiB are the per-XCD counters of the persistent walk, which every launch leaves at zero."""
+    once: its first 4 KiB are the per-XCD counters of the persistent walk, which every launch leaves at zero.  Under stream capture
+    (the UNet inside a hipGraph) the buffer comes from the graph's pool; only the counter page is zeroed there (one 4 KiB fill node
+    per replay instead of a 128 MiB one: the slabs need no initialisation)."""
     key = (device, torch.cuda.current_stream(device).cuda_stream)
     ws = _STREAMK_WS.get(key)
     if ws is None:
-        ws = _STREAMK_WS[key] = torch.zeros(int(_lib.call("dllm_gemm_streamk_ws_bytes")) // 4, dtype=torch.float32, device=device)
+        n = int(_lib.call("dllm_gemm_streamk_ws_bytes")) // 4
+        if torch.cuda.is_current_stream_capturing():
+            ws = torch.empty(n, dtype=torch.float32, device=device)
+            ws[:1024].zero_()
+        else:
+            ws = torch.zeros(n, dtype=torch.float32, device=device)
+        _STREAMK_WS[key] = ws
     return ws
 
 
@@ -250,10 +258,10 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     sk = _lib.call("dllm_gemm_splitk_hint", M, N, K) if SPLITK else 1
     ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
     persist = 0
-    if sk == 1 and (GEMM_VARIANT & 0xffff) in (0, 259) and not torch.cuda.is_current_stream_capturing():
+    if sk == 1 and (GEMM_VARIANT & 0xffff) in (0, 259):
         if STREAMK and _streamk_hint(M, N, K, layout_a, layout_b):
             ws = _streamk_workspace(a.device)   # the library spreads the last partial round of 256-tiles over the CUs (stream-K tail)
-        if GEMM_PERSIST and -(-M // 256) * -(-N // 256) >= 1024 and K % 64 == 0:
+        if GEMM_PERSIST and -(-M // 256) * -(-N // 256) >= 1024 and K % 64 == 0 and not torch.cuda.is_current_stream_capturing():
             ws = _streamk_workspace(a.device)
             persist = 1 << 24
     cnt = _splitk_counters(a.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-M // 128) * -(-N // 128) <= 16384) else None
@@ -1046,6 +1054,8 @@ def conv2d_nhwc(x, w2d, CO, KH, KW, stride=1, pad=1, OH=None, OW=None, bias=None
     sk = _lib.call("dllm_gemm_splitk_hint", Mg, CO, KH * KW * C) if SPLITK else 1
     ws = torch.empty(sk * Mg * CO, dtype=torch.float32, device=x.device) if sk > 1 else None
     cnt = _splitk_counters(x.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-Mg // 128) * -(-CO // 128) <= 16384) else None
+    if sk == 1 and STREAMK and GEMM_VARIANT == 0 and C % 64 == 0 and _streamk_hint(Mg, CO, KH * KW * C, 2, 0):
+        ws = _streamk_workspace(x.device)   # small grid, deep K: every tile's K loop is spread over the CUs (stream-K)
     with _GemmTimer(2.0 * N * OH * OW * CO * KH * KW * C, "conv"):
         check("dllm_conv2d_nhwc_bf16_splitk", _p(x), _p(w2d), _p(out), _p(bias), _p(residual), _p(image_bias), N, H, W, C, OH,
               OW, CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), sk, _p(ws), _p(cnt), GEMM_VARIANT, _stream())

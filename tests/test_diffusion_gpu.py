@@ -70,6 +70,39 @@ def test_conv_fwd_dgrad(N, H, W, CI, CO, K, mode, tile):
     _o.GEMM_VARIANT = 0
 
 
+@pytest.mark.parametrize("mode,CI", [("same", 1280), ("same", 2560), ("up", 1280)])
+def test_conv_streamk_small_grid(mode, CI):
+    """The UNet's 1280-channel 3x3 convs at 16 x 16 and batch 16 (M = 4096 -> 80 tiles of 256 x 256, K = 11520 / 23040): every tile's K
+    loop goes through the stream-K machinery (`streamk_plan_small`), including the fused-upsample gather and the per-image bias /
+    residual epilogue applied by the fix-up launch.  Against the whole-tile launch (ops.STREAMK = False), run-to-run bit-identical,
+    and against F.conv2d in fp32 on the GPU."""
+    from dreamllm_amd import _lib
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(CI)
+    N, H, CO = 16, (8 if mode == "up" else 16), 1280
+    x = torch.randn(N, H, H, CI, device=DEV, generator=g).to(BF)
+    w = (torch.randn(CO, 3, 3, CI, device=DEV, generator=g) / math.sqrt(9 * CI)).to(BF)
+    b = (0.1 * torch.randn(CO, device=DEV, generator=g)).to(BF)
+    OH = 2 * H if mode == "up" else H
+    res = torch.randn(N, OH, OH, CO, device=DEV, generator=g).to(BF)
+    tb = torch.randn(N, CO, device=DEV, generator=g).to(BF)
+    assert _lib.call("dllm_gemm_streamk_hint", N * OH * OH, CO, 9 * CI, 2, 0) == 1
+    run = lambda: ops.conv2d_nhwc(x, w.reshape(CO, -1), CO, 3, 3, bias=b, residual=res, image_bias=tb, up2=(mode == "up"))
+    y1 = run()
+    ops.STREAMK = False
+    try:
+        y0 = run()
+    finally:
+        ops.STREAMK = True
+    assert torch.equal(run(), y1)
+    assert rel_l2(y1, y0.float()) < 2e-3
+    xr = x.float().permute(0, 3, 1, 2)
+    if mode == "up":
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xr, w.float().permute(0, 3, 1, 2), b.float(), padding=1) + tb.float()[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    assert rel_l2(y1.permute(0, 3, 1, 2), ref) < 4e-3
+
+
 def test_conv_epilogue_image_bias_and_residual():
     from dreamllm_amd.unet import HipConv2d
     torch.manual_seed(3)
