@@ -227,7 +227,8 @@ __global__ __launch_bounds__(1024) void gn_small_kernel(const bf16* __restrict__
 // different XCDs, whose L2s are not coherent for plain accesses).  Every block publishes its sums, waits until they have completed,
 // takes a ticket; the last arriver zeroes the count and bumps the epoch, the others spin on the epoch they read before arriving.  The
 // totals are then summed in slot order by every block: deterministic, identical in all S blocks.  All NB * G * S blocks are
-// co-resident by construction (host: at most 512 blocks of 1024 threads), so the wait cannot deadlock.
+// co-resident by construction (host: at most 512 blocks of 1024 threads); should they not be (a GPU shared between processes), a
+// block that waited ~2 ms computes the whole slice's statistics itself: the wait cannot deadlock and cannot produce a wrong result.
 template <int S>
 __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gamma,
                                                               const bf16* __restrict__ beta, bf16* __restrict__ y,
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
                                                               unsigned* __restrict__ sync, int HW, int C, int G, float eps, int act) {
     __shared__ float red[32];
     __shared__ float tot[2];
+    __shared__ int alone;
     const int grp = blockIdx.x / S, part = blockIdx.x - grp * S;
     const int n = grp / G, g = grp - n * G;
     const int cpg = C / G, pp = cpg >> 1;
@@ -277,12 +279,21 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
         __hip_atomic_store(fs + 2 * part + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // published before the ticket is taken
         const unsigned old = __hip_atomic_fetch_add(slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
         if (old == (unsigned)(S - 1)) {
             __hip_atomic_store(slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_fetch_add(slot + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            while (__hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f0) __builtin_amdgcn_s_sleep(1);
+            // ~2 ms of polling, then give up on the partners (a GPU shared with other processes can keep them from being
+            // co-resident): the block then computes the statistics of the whole (image, group) slice itself -- slower, never wrong,
+            // never stuck.  The ticket protocol stays consistent: the late partners still arrive and the last one resets the count.
+            int spin = 0;
+            while (__hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == f0 && spin < (1 << 15)) {
+                __builtin_amdgcn_s_sleep(8);
+                ++spin;
+            }
+            ok = spin < (1 << 15);
         }
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -292,8 +303,29 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
         }
         tot[0] = t1;
         tot[1] = t2;
+        alone = ok ? 0 : 1;
     }
     __syncthreads();
+    if (alone) {   // (uniform) statistics over ALL pixels of the slice, by this block alone
+        float a1 = 0.f, a2 = 0.f;
+        if (live) {
+            const bf16* px = x + base + (int64_t)r * C;
+            for (int p = r; p < HW; p += R, px += stride) {
+                const bf16x2 v = *reinterpret_cast<const bf16x2*>(px);
+                const float a = (float)v[0], b = (float)v[1];
+                a1 += a + b;
+                a2 += a * a + b * b;
+            }
+        }
+        __syncthreads();
+        a1 = block_sum<16>(a1, red);
+        a2 = block_sum<16>(a2, red + 16);
+        if (threadIdx.x == 0) {
+            tot[0] = a1;
+            tot[1] = a2;
+        }
+        __syncthreads();
+    }
     const float cnt = (float)HW * (float)cpg;
     const float mean = tot[0] / cnt;
     const float rstd = rsqrtf(fmaxf(tot[1] / cnt - mean * mean, 0.f) + eps);
