@@ -7,6 +7,8 @@ from __future__ import annotations
 import ctypes
 import os
 
+import torch  # noqa: F401  -- before the library is dlopen'ed: it must bind to the HIP runtime the PyTorch-ROCm wheel loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DREAMLLM_HIP_LIB") or os.path.join(_HERE, "libdreamllm_hip.so")
 
