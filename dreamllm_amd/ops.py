@@ -248,6 +248,27 @@ def _streamk_workspace(device):
 GEMM_PERSIST = os.environ.get("DREAMLLM_GEMM_PERSIST", "0") == "1"
 
 
+# Experiment knob (tools only): DREAMLLM_SPLITK_WANT=n replaces the library's split-K target for tiny grids (blocks the split aims
+# at: 384 in dllm_gemm_splitk_hint) so that denoise-loop A/B runs need no rebuild.  Unset = the library's own hint.
+_SPLITK_WANT = int(os.environ.get("DREAMLLM_SPLITK_WANT", "0"))
+
+
+def _splitk_hint(M, N, K):
+    if not SPLITK:
+        return 1
+    if _SPLITK_WANT <= 0:
+        return _lib.call("dllm_gemm_splitk_hint", M, N, K)
+    if M <= 0 or N <= 0 or (N & 3):
+        return 1
+    tiles = -(-M // 128) * -(-N // 128)
+    ktiles = -(-K // 64)
+    if tiles > 256 or ktiles < 16:
+        return 1
+    want = (512 // tiles) if tiles >= 128 else -(-_SPLITK_WANT // tiles)
+    s = min(want, ktiles // 8, 32)
+    return 1 if s < 2 else int(s)
+
+
 def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=torch.bfloat16, bias=None, residual=None,
          ldr=0, epi=None, accumulate=False, alpha=1.0):
     """C[M,N] = A*B; layout_a 0: A[m][k] k-contiguous, 1: stored [K][lda]; layout_b 0: B as [N][ldb], 1: [K][ldb]."""
@@ -255,7 +276,7 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     _bf16(a, b, bias, residual)
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
-    sk = _lib.call("dllm_gemm_splitk_hint", M, N, K) if SPLITK else 1
+    sk = _splitk_hint(M, N, K)
     ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
     persist = 0
     if sk == 1 and (GEMM_VARIANT & 0xffff) in (0, 259):
@@ -1051,7 +1072,7 @@ def conv2d_nhwc(x, w2d, CO, KH, KW, stride=1, pad=1, OH=None, OW=None, bias=None
     if residual is not None and not residual.is_contiguous():
         residual = residual.contiguous()
     Mg = N * OH * OW
-    sk = _lib.call("dllm_gemm_splitk_hint", Mg, CO, KH * KW * C) if SPLITK else 1
+    sk = _splitk_hint(Mg, CO, KH * KW * C)
     ws = torch.empty(sk * Mg * CO, dtype=torch.float32, device=x.device) if sk > 1 else None
     cnt = _splitk_counters(x.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-Mg // 128) * -(-CO // 128) <= 16384) else None
     if sk == 1 and STREAMK and GEMM_VARIANT == 0 and C % 64 == 0 and _streamk_hint(Mg, CO, KH * KW * C, 2, 0):
