@@ -86,3 +86,24 @@ def test_ctypes_signatures_match_header_prototypes():
         assert c_args == py_args, (name, c_args, py_args)
         checked += 1
     assert checked == len(set(n for n, _ in protos))
+
+
+def test_scheduling_hints_are_pure_host_functions():
+    """The split-K / stream-K plans are host arithmetic of the library (no device needed): pin them at the shapes the bench runs, so
+    a change of the plan shows up here and not as a silent throughput change.  T = 16 x 2048 tokens, d = 4096, F = 11008."""
+    from dreamllm_amd import _lib
+    T, d, F_ = 32768, 4096, 11008
+    sk = lambda M, N, K, la, lb: _lib.call("dllm_gemm_streamk_hint", M, N, K, la, lb)
+    # stream-K tail: only the packed gate|up weight gradient (1376 tiles = 5 rounds + 96)
+    assert sk(2 * F_, d, T, 1, 1) == 1
+    for shape in [(d, F_, T, 1, 1), (3 * d, d, T, 1, 1), (d, d, T, 1, 1), (T, F_, d, 0, 1), (T, 2 * F_, d, 0, 0), (T, d, d, 0, 0),
+                  (T, d, F_, 0, 0), (T, 3 * d, d, 0, 0), (T, d, 2 * F_, 0, 1)]:
+        assert sk(*shape) == 0, shape
+    # small grid, deep K (layout 2 = implicit-GEMM conv): the UNet's 1280-channel 3x3 convs at 16 x 16, batch 16 and 32
+    assert sk(16 * 256, 1280, 9 * 1280, 2, 0) == 1 and sk(32 * 256, 1280, 9 * 2560, 2, 0) == 1
+    assert sk(2 * 256, 1280, 9 * 1280, 2, 0) == 0           # batch 2: 10 tiles -> the split-K kernels
+    assert sk(16 * 4096, 320, 9 * 320, 2, 0) == 0           # 512 tiles: whole rounds
+    # split-K of tiny grids (the denoise loop at batch 2)
+    h = lambda M, N, K: _lib.call("dllm_gemm_splitk_hint", M, N, K)
+    assert h(T, d, d) == 1 and h(512, 1280, 11520) == 10 and h(128, 1280, 11520) == 22 and h(8192, 320, 2880) == 2
+    assert _lib.call("dllm_gemm_streamk_ws_bytes") == (2 * 256 * 256 * 256 + 1024) * 4
