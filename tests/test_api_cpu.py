@@ -305,3 +305,36 @@ def test_rope_scaling_variants_match_the_executed_reference(golden):
             cos, sin = rot(x, seq_len=st["seq_len"])
             assert cos.shape == st["cos"].shape
             assert (cos - st["cos"]).abs().max() < 2e-5 and (sin - st["sin"]).abs().max() < 2e-5, (c["type"], c["factor"], st["seq_len"])
+
+
+def test_unet_time_bias_layout_and_mask_span_errors():
+    """Host-side pieces of round 3 that need no kernel: (i) the flat time-bias buffer of `HipUNet2DConditionModel.precompute_time_bias`
+    -- one [N, cout] slice per ResnetBlock2D in execution order, contiguous, 22 blocks for the SD-2.1 layout; (ii) `_mask_to_spans`:
+    left / right padding become spans, a mask with holes raises `_MaskHasHoles` (the model then compacts), 4-D masks are rejected."""
+    import pytest
+    from dreamllm_amd.modeling_dreamllm import _mask_to_spans, _MaskHasHoles
+    from dreamllm_amd.unet import SD21_BASE, HipUNet2DConditionModel, load_unet_config
+    with torch.device("meta"):
+        unet = HipUNet2DConditionModel(load_unet_config(dict(SD21_BASE)))
+    res = unet._resnets()
+    assert len(res) == 22 and res[0] is unet.down_blocks[0].resnets[0] and res[-1] is unet.up_blocks[-1].resnets[-1]
+    offs, total = unet.time_bias_layout(2)
+    assert offs[0] == (0, 320) and total == 2 * sum(c for _, c in offs)
+    for (o0, c0), (o1, _) in zip(offs, offs[1:]):
+        assert o1 == o0 + 2 * c0
+    assert sorted({c for _, c in offs}) == [320, 640, 1280]
+    am = torch.ones(3, 10, dtype=torch.long)
+    assert _mask_to_spans(am) == (None, None)
+    am[1, 7:] = 0
+    start, lens = _mask_to_spans(am)
+    assert start is None and lens.tolist() == [10, 7, 10]
+    am2 = torch.ones(2, 10, dtype=torch.long)
+    am2[0, :3] = 0
+    start, lens = _mask_to_spans(am2)
+    assert start.tolist() == [3, 0] and lens.tolist() == [7, 10]
+    am2[1, 4] = 0
+    with pytest.raises(_MaskHasHoles):
+        _mask_to_spans(am2)
+    assert issubclass(_MaskHasHoles, ValueError)
+    with pytest.raises(ValueError):
+        _mask_to_spans(torch.zeros(2, 1, 4, 4))
