@@ -30,6 +30,7 @@ PEAK_BF16_TFLOPS = 2500.0  # dense MFMA peak, /opt/skills/guides/MI355X_MICROARC
 # analytic algorithmic FLOPs (multiply-add = 2), SURVEY.md §8(d)
 FLOPS_TRAIN_SAMPLE = 88.1e12
 FLOPS_UNET_FWD = 0.803e12
+FLOPS_LM_HEAD_TOKEN = 2 * 4096 * 32000  # lm_head forward per token (0.262 GFLOP); x3 with both gradients
 
 
 def parse():
@@ -131,8 +132,10 @@ def cpu_baseline(seq_len, budget_s=60.0):
     del usd
     K = 2
     t_sample = 32 * t_layer + t_head + K * (t_clip or 0.0) + K * t_unet2  # K_g images x (fwd + dgrad ~ 2 fwd) = K x one batch-2 fwd x 2 / 2
+    timing = "one warm-up per piece, then " + ", ".join(
+        f"{n}: {'median of 3 runs' if r == 3 else f'{r} run (three more would not fit the {budget_s:.0f} s budget)'}" for n, r in reps_used.items())
     return dict(value=1.0 / t_sample, unit="samples/s", cores=torch.get_num_threads(), kind="port",
-                denoise_steps_per_s=round(1.0 / t_unet2, 4), timing="median of 3 after one warm-up per piece", runs_per_piece=reps_used,
+                denoise_steps_per_s=round(1.0 / t_unet2, 4), timing=timing, runs_per_piece=reps_used,
                 sample=f"oracle ports (CLIP: installed transformers class), fp32: decoder layer fwd+bwd B=1 S={S} ({t_layer:.2f} s, x32) + lm_head/CE "
                        f"({t_head:.2f} s) + CLIP-L/14 fwd ({'n/a' if t_clip is None else f'{t_clip:.2f} s'}, x{K}) + SD-2.1 UNet CFG "
                        f"step batch 2 ({t_unet2:.2f} s = the CPU denoise step; x{K} stands for fwd+dgrad of {K} dream images); "
@@ -290,6 +293,10 @@ def main():
             d[2] += 1
         samples = world * a.batch * a.steps
         value = samples / dt
+        # share of the S rows of a sample that carry an LM label (after the shift): what the fused lm_head + CE unit runs on
+        lab = batch.get("labels")
+        lab_share = float((lab[:, 1:] != -100).sum().item()) / float(lab.shape[0] * lab.shape[1]) if torch.is_tensor(lab) else 1.0
+        flops_required = FLOPS_TRAIN_SAMPLE - 3 * FLOPS_LM_HEAD_TOKEN * a.seq_len * (1.0 - lab_share)
         achieved = gsum / tsum / 1e12 if tsum > 0 else 0.0
         # HBM-side bytes of one launch of the dominant shape, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
         # (profiles/roofline_traffic.json; corrected as MI355X_MICROARCH.md prescribes).  A number, per launch, like `achieved`.
@@ -310,12 +317,16 @@ def main():
             value=value, ms_per_step=1e3 * dt / a.steps, loss=loss_val,
             roofline=dict(bound="mfma", kernel="bf16 MFMA GEMM family: gemm_pipe_kernel / gemm_bf16_kernel (linear fwd/dgrad/wgrad + implicit-GEMM conv)",
                           achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
-                          traffic=traffic, traffic_detail=traffic_detail, launches_per_step=len(prof) // max(a.steps, 1),
+                          traffic=traffic, traffic_measured=False, traffic_detail=traffic_detail, launches_per_step=len(prof) // max(a.steps, 1),
                           avg_launch_ms=round(1e3 * tsum / max(len(prof), 1), 4),
                           time_share_of_step=round(tsum / dt, 4),
                           by_kind={k: dict(tflops=round(v[0] / v[1] / 1e12, 1), launches=v[2] // max(a.steps, 1))
                                    for k, v in by_tag.items() if v[1] > 0}),
-            e2e_frac_mfma_peak=None if tiny else round(value / world * FLOPS_TRAIN_SAMPLE / (PEAK_BF16_TFLOPS * 1e12), 4),
+            # SURVEY §8(d)'s 88.1 TFLOP / sample counts lm_head fwd + bwd on all S rows; the step computes it on the labelled rows only
+            # (the rest of an interleaved document carries no LM loss): the headline fraction uses the FLOPs the step REQUIRES
+            e2e_frac_mfma_peak=None if tiny else round(value / world * flops_required / (PEAK_BF16_TFLOPS * 1e12), 4),
+            e2e_frac_mfma_peak_full_lm_head=None if tiny else round(value / world * FLOPS_TRAIN_SAMPLE / (PEAK_BF16_TFLOPS * 1e12), 4),
+            flops_per_sample=dict(required=flops_required, survey_8d=FLOPS_TRAIN_SAMPLE, labelled_row_share=round(lab_share, 4)),
             peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1),
             comm=comm,
         )

@@ -567,9 +567,20 @@ class CausalLMOutputWithPast(ModelOutput):
     attentions: tuple[torch.FloatTensor] | None = None
     additional_log_info: dict[str, Any] | None = None
 
-    def set_lazy_logits(self, thunk):
+    def set_lazy_logits(self, thunk, bulk_views=True):
+        """`bulk_views=False` (set by the TRAINING forward, grad enabled): the mapping views that plumbing walks every step --
+        `items()` / `values()` / `keys()` / iteration / `len()`: accelerate's `convert_outputs_to_fp32`, DDP's output flattening --
+        leave pending logits out, exactly as for a `None` field, so the [B, S, V] GEMM never runs for a caller that only reads the
+        loss (omni/train/trainer.py:1083,1092 read `outputs["loss"]` / `outputs["additional_log_info"]`).  Explicit requests still
+        materialise them: `.logits`, `["logits"]`, `"logits" in out`, integer / slice indexing and `to_tuple()`.  With
+        `bulk_views=True` (eval / no_grad: `Trainer.prediction_step` walks `outputs.items()` FOR the logits) the bulk views
+        materialise too and show `logits` in slot 1 as the reference returns it."""
         object.__setattr__(self, "_logits_thunk", thunk)
+        object.__setattr__(self, "_logits_bulk", bool(bulk_views))
         return self
+
+    def _pending(self):
+        return self.__dict__.get("_logits_thunk") is not None
 
     def _materialize_logits(self):
         thunk = self.__dict__.get("_logits_thunk")
@@ -585,6 +596,10 @@ class CausalLMOutputWithPast(ModelOutput):
                 self.move_to_end(f.name)
         return val
 
+    def _bulk(self):
+        if self._pending() and self.__dict__.get("_logits_bulk", True):
+            self._materialize_logits()
+
     def __getattribute__(self, name):
         if name == "logits":
             val = super().__getattribute__("logits")
@@ -593,27 +608,27 @@ class CausalLMOutputWithPast(ModelOutput):
             return val
         return super().__getattribute__(name)
 
-    # Every positional / mapping view materialises pending logits first, so tuple-style consumers (`out[1]`, `out.to_tuple()`,
-    # `dict(out)`, HF Trainer.prediction_step's `outputs.items()`) see `logits` in its dataclass position.  Attribute access to
-    # `loss` (all the training loop reads) stays free.
+    # String keys other than "logits" (`out["loss"]`, `out["additional_log_info"]`: all the reference trainer reads) and attribute
+    # access never touch the thunk.  Positional access (`out[1]`, slices, `to_tuple()`) is a request for the reference's tuple
+    # layout and materialises; the bulk mapping views follow `bulk_views` (see set_lazy_logits).
     def keys(self):
-        self._materialize_logits()
+        self._bulk()
         return super().keys()
 
     def values(self):
-        self._materialize_logits()
+        self._bulk()
         return super().values()
 
     def items(self):
-        self._materialize_logits()
+        self._bulk()
         return super().items()
 
     def __iter__(self):
-        self._materialize_logits()
+        self._bulk()
         return super().__iter__()
 
     def __len__(self):
-        self._materialize_logits()
+        self._bulk()
         return super().__len__()
 
     def __contains__(self, k):
@@ -622,7 +637,8 @@ class CausalLMOutputWithPast(ModelOutput):
         return super().__contains__(k)
 
     def __getitem__(self, k):
-        self._materialize_logits()
+        if not isinstance(k, str) or k == "logits":
+            self._materialize_logits()
         return super().__getitem__(k)
 
     def to_tuple(self):
@@ -1059,7 +1075,7 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
                                      hidden_states=outputs.hidden_states, attentions=None,
                                      additional_log_info=additional_log_info)
         if lazy_logits is not None:
-            out.set_lazy_logits(lazy_logits)
+            out.set_lazy_logits(lazy_logits, bulk_views=not (self.training and torch.is_grad_enabled()))
         return out
 
     def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kwargs):

@@ -290,6 +290,41 @@ def test_lazy_logits_keep_the_model_output_contract():
     assert list(eager.keys()) == ["loss", "logits", "past_key_values"]
 
 
+def test_lazy_logits_stay_lazy_for_the_training_plumbing():
+    """the reference trainer reads `outputs["loss"]` / `outputs["additional_log_info"]` (omni/train/trainer.py:1083,1092)
+    and accelerate's `convert_outputs_to_fp32` / DDP walk `items()` / `values()` every step: none of that may run the [B, S, V]
+    lm_head GEMM.  The training forward marks its output `bulk_views=False`; explicit requests still materialise."""
+    from dreamllm_amd.modeling_dreamllm import CausalLMOutputWithPast
+    calls = []
+
+    def thunk():
+        calls.append(1)
+        return torch.full((2, 3), 7.0)
+
+    def make(bulk):
+        return CausalLMOutputWithPast(loss=torch.tensor(1.0), hidden_states=(torch.zeros(1),),
+                                      additional_log_info={"lm_loss": 1.0}).set_lazy_logits(thunk, bulk_views=bulk)
+
+    o = make(False)
+    assert float(o["loss"]) == 1.0 and o["additional_log_info"]["lm_loss"] == 1.0 and not calls
+    assert [k for k, _ in o.items()] == ["loss", "hidden_states", "additional_log_info"] and len(o) == 3 and not calls
+    assert len(list(o.values())) == 3 and list(o) == list(o.keys()) and "loss" in o and not calls
+    try:   # accelerate.utils.operations.convert_to_fp32 is what `convert_outputs_to_fp32` applies to a training forward's output
+        from accelerate.utils.operations import convert_to_fp32
+        conv = convert_to_fp32(o)
+        assert float(conv["loss"]) == 1.0 and not calls
+    except ImportError:
+        pass
+    assert o["logits"].shape == (2, 3) and len(calls) == 1                 # an explicit request still gets them, in slot 1
+    assert list(o.keys()) == ["loss", "logits", "hidden_states", "additional_log_info"]
+    o = make(False)
+    assert o[1].shape == (2, 3) and len(o.to_tuple()) == 4 and len(calls) == 2
+    o = make(False)
+    assert "logits" in o and o.logits.shape == (2, 3) and len(calls) == 3
+    o = make(True)   # eval / no_grad outputs: the bulk views materialise (Trainer.prediction_step walks items() for the logits)
+    assert [k for k, _ in o.items()] == ["loss", "logits", "hidden_states", "additional_log_info"] and len(calls) == 4
+
+
 def test_rope_scaling_variants_match_the_executed_reference(golden):
     """`rope_scaling = {"type": "linear" | "dynamic", "factor": f}` (modeling_dreamllm.py:131-173, selected at :279-304): the cos / sin
     tables of `RotaryEmbedding.forward` against the executed reference classes, in a call order that includes sequences beyond
