@@ -21,18 +21,10 @@
 // transpose read ds_read_b64_tr_b16, so no operand is ever transposed in HBM.  The MFMA is issued with the operands
 // swapped (D^T = B^T A^T) so every lane ends up with 4 consecutive output columns of one row -> 8/16-byte stores.
 // blockIdx is remapped so each XCD (private 4 MiB L2) works on a contiguous group of tiles (GROUP_M swizzle).
-#include <type_traits>
-
-#include "common.h"
+#include "gemm_shared.h"
 
 namespace {
 
-constexpr int BK = 64;
-constexpr int A_K = 0, A_M = 1, A_CONV = 2;
-constexpr int A_CONVS = 3;  // pipelined kernel only: conv gather with "shift" addressing (fused nearest-2x upsample / transposed stride-2)
-constexpr int B_K = 0, B_N = 1;
-
-constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
 
 // Kernel choice is a per-call argument (`variant`, see include/dreamllm_hip.h): the library keeps no mutable state.
 struct Variant {
@@ -43,11 +35,12 @@ struct Variant {
     int group_m = 0;     // 0: per-layout default
     int force_n128 = 0;  // tile code 262: the 256 x 128 pipelined kernel wherever it is eligible (tests)
     int persist = 0;     // bit 24: XCD-synchronised persistent walk of the pipelined 256-tile kernel (needs the workspace)
+    int force_ring = 0;  // tile code 264: the 128 x 128 ring-buffered kernel (gemm_ring.hip) wherever it is eligible (tests, tools)
 };
 static inline int parse_variant(int variant, Variant& v) {
     const int tile = variant & 0xffff;
     v.group_m = (variant >> 16) & 0xff;
-    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262;
+    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262 || tile == 264;
 #ifdef DLLM_BENCH_MODES
     ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265;
     v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
@@ -58,76 +51,12 @@ static inline int parse_variant(int variant, Variant& v) {
     v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 262 || tile == 263 || tile == 265);
     v.force_tile = tile >= 257 ? 256 : tile;
     v.force_n128 = tile == 262;
+    v.force_ring = tile == 264;
+    if (v.force_ring) v.force_tile = 0;
     return DLLM_OK;
 }
 
-struct ConvGeom {
-    int H, W, C;     // physical input spatial dims and channels (NHWC)
-    int OH, OW;      // output spatial dims
-    int KH, KW;      // 3x3 or 1x1
-    int stride;      // 1 or 2 (forward)
-    int pad;         // 1 for 3x3, 0 for 1x1
-    int up_shift;    // 1: logical input is the nearest-2x upsampled image (physical = logical >> 1)
-    int even_only;   // 1: transposed (dgrad of a stride-2 conv): logical index must be even, physical = logical >> 1
-};
 
-struct GemmParams {
-    const bf16* A;
-    const bf16* B;
-    void* C;
-    const bf16* bias;      // [N] or null
-    const bf16* residual;  // [M, ldr] or null (added after activation)
-    const bf16* rg_bias;   // [M / rg_rows, N] or null: per-row-group bias (UNet time embedding per image), before activation
-    int64_t rg_rows;
-    int64_t M, N, K;
-    int64_t lda, ldb, ldc, ldr;
-    int epi;
-    int out_f32;     // C dtype
-    int accumulate;  // C += result
-    float alpha;     // scale applied to the accumulator before bias
-    int group_m;     // tiles per column group of the grouped tile order (pipe kernel; default 8)
-    int dbg_noload;  // benchmark-only: skip the K-loop prefetches (wrong results) to expose the compute+barrier ceiling
-    int splitk;      // > 1: blockIdx.y owns a K range and writes raw fp32 partials to ws[split][M][N]
-    float* ws;
-    int sk_full;     // stream-K tail: tiles of the grouped order covered by the whole-round launch (0 = every tile, no tail)
-    int sk_tail;     //                tiles whose K loops the tail kernel spreads over the CUs
-    int sk_w;        //                K tiles per tail block
-    int* counters;   // split-K: one arrival counter per output tile (zero on entry, left zero): the last K slice reduces in-kernel
-    ConvGeom cv;
-};
-
-// ---- LDS images -------------------------------------------------------------------------------------------------
-// k-contiguous tile: [128 rows][64 k] bf16, 128 B per row, 16-B chunk c stored at chunk c ^ ((row >> 1) & 7):
-// conflict-free for ds_read_b128 fragment reads (16 distinct rows, same chunk) and for the staging ds_write_b128.
-__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-// m-contiguous tile: [64 k rows][128 m] bf16, 256 B per row, 32-B slot s stored at s ^ f(krow),
-// f = (krow & 3) | ((krow >> 3) & 1) << 2: the 8 k rows one half-wave touches in a transpose read hit 8 distinct slots.
-template <int T>
-__device__ __forceinline__ int mc_off(int krow, int byte_in_row) {
-    const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
-    return krow * (2 * T) + ((((byte_in_row >> 5) ^ f)) << 5) + (byte_in_row & 31);
-}
-
-__device__ __forceinline__ bf16x8 frag_kc(const char* tile, int row, int kk, int lane) {
-    return *reinterpret_cast<const bf16x8*>(tile + kc_off(row, kk * 4 + (lane >> 4)));
-}
-
-template <int T>
-__device__ __forceinline__ bf16x8 frag_mc(const char* tile, int mbase, int kk, int lane) {
-    // lane (g = lane>>4, t = lane&15) receives m = mbase + t, k = kk*32 + g*8 + 0..7
-    const int g = lane >> 4, t = lane & 15;
-    const int k0 = kk * 32 + g * 8 + (t >> 2);
-    const int bcol = mbase * 2 + (t & 3) * 8;
-    short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + mc_off<T>(k0, bcol)));
-    short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(short4v, tile + mc_off<T>(k0 + 4, bcol)));
-    union {
-        struct { short4v a, b; } s;
-        bf16x8 v;
-    } u;
-    u.s.a = lo;
-    u.s.b = hi;
-    return u.v;
-}
 
 // ---- global -> register staging -----------------------------------------------------------------------------------
 struct Stage {
@@ -272,288 +201,6 @@ __device__ __forceinline__ void gload_conv(Stage& s, const bf16* base, const Con
     }
 }
 
-// ---- epilogue shared by both kernels: lane holds C[m][n..n+3], m = mbase+i*16+(lane&15), n = nbase+j*16+(lane>>4)*4
-// bias / per-image bias / activation / residual / dtype conversion for 4 consecutive outputs C[m][n..n+3]
-__device__ __forceinline__ void epilogue_store4(const GemmParams& P, int64_t m, int64_t n, float (&v)[4], bool vec_ok) {
-    const int nvalid = (int)min((int64_t)4, P.N - n);
-    if (P.bias != nullptr) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nvalid) v[r] += (float)P.bias[n + r];
-    }
-    if (P.rg_bias != nullptr) {
-        const bf16* rb = P.rg_bias + (m / P.rg_rows) * P.N + n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nvalid) v[r] += (float)rb[r];
-    }
-    if (P.epi == EPI_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
-    } else if (P.epi == EPI_QUICK_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
-    } else if (P.epi == EPI_SILU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-    }
-    if (vec_ok && nvalid == 4) {
-        if (P.residual != nullptr) {
-            bf16x4 rv = ld_bf16x4(P.residual + m * P.ldr + n);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-        }
-        if (P.out_f32) {
-            float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n;
-            f32x4 o = f32x4{v[0], v[1], v[2], v[3]};
-            if (P.accumulate) o += *reinterpret_cast<f32x4*>(cp);
-            *reinterpret_cast<f32x4*>(cp) = o;
-        } else {
-            bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n;
-            if (P.accumulate) {
-                bf16x4 c = ld_bf16x4(cp);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)c[r];
-            }
-            bf16x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (bf16)v[r];
-            st_bf16x4(cp, o);
-        }
-    } else {
-        for (int r = 0; r < nvalid; ++r) {
-            float x = v[r];
-            if (P.residual != nullptr) x += (float)P.residual[m * P.ldr + n + r];
-            if (P.out_f32) {
-                float* cp = reinterpret_cast<float*>(P.C) + m * P.ldc + n + r;
-                *cp = P.accumulate ? (*cp + x) : x;
-            } else {
-                bf16* cp = reinterpret_cast<bf16*>(P.C) + m * P.ldc + n + r;
-                *cp = (bf16)(P.accumulate ? ((float)*cp + x) : x);
-            }
-        }
-    }
-}
-
-// ---- epilogue shared by the kernels: lane holds C[m][n..n+3], m = mbase+i*16+(lane&15), n = nbase+j*16+(lane>>4)*4
-template <int MI>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[MI][4], int64_t mbase, int64_t nbase, int lane,
-                                              int split = 0, int tile = 0, int* lds_flag = nullptr) {
-    const bool vec_ok = ((P.N & 3) == 0) && ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
-    if (P.dbg_noload == 3 && acc[0][0][0] != 12345.678f) return;  // benchmark-only: no C stores (the test keeps acc live)
-    if (P.splitk > 1) {
-        // raw fp32 partial slab of this K slice (N % 4 == 0 enforced by the host)
-        const bool fused = P.counters != nullptr && lds_flag != nullptr;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int64_t m = mbase + i * 16 + (lane & 15);
-            if (m >= P.M) continue;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t n = nbase + j * 16 + (lane >> 4) * 4;
-                if (n >= P.N) continue;
-                float* dst = P.ws + ((int64_t)split * P.M + m) * P.N + n;
-                if (fused)  // write-through (sc1): the slab is visible at agent scope without a whole-L2 write-back
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(acc[i][j]) : "memory");
-                else
-                    *reinterpret_cast<f32x4*>(dst) = acc[i][j];
-            }
-        }
-        if (!fused) return;  // the separate reduce kernel follows
-        // In-kernel reduction: every K slice of a tile publishes its slab with write-through stores (the other slices run on other
-        // XCDs, whose L2s are not coherent with this one; a release fence = whole-L2 write-back per block measured 1.5x SLOWER than
-        // the separate reduce kernel) and takes a ticket once all its stores have completed; the slice that draws the last ticket
-        // invalidates (agent-scope acquire), sums the slabs in slice order (deterministic: the order of splitk_reduce_kernel) and
-        // applies the epilogue.  One launch less per split GEMM: ~140 per denoising step of the UNet at batch 2.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0)
-            *lds_flag = __hip_atomic_fetch_add(P.counters + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*lds_flag != P.splitk - 1) return;
-        if (threadIdx.x == 0) __hip_atomic_store(P.counters + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the slabs are read with agent-coherent loads (sc0 sc1: they miss this XCD's caches) instead of an acquire fence: a
-        // buffer_inv per reducing block empties the XCD's L2 under every other block of the launch (measured 109 -> 75 steps/s).
-        // All loads of one slice are in flight together (MI * 4 requests per lane), slices are summed in order.
-        f32x4 sum[MI][4];
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) sum[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < P.splitk; ++z) {
-            f32x4 t[MI][4];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int64_t m = min(mbase + i * 16 + (lane & 15), P.M - 1);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int64_t n = min(nbase + j * 16 + (lane >> 4) * 4, P.N - 4);
-                    const float* src = P.ws + ((int64_t)z * P.M + m) * P.N + n;
-                    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(t[i][j]) : "v"(src) : "memory");
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (i == 0 && j == 0)
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(t[0][0]) : : "memory");
-                    else
-                        asm volatile("" : "+v"(t[i][j]));
-                    sum[i][j] += t[i][j];
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int64_t m = mbase + i * 16 + (lane & 15);
-            if (m >= P.M) continue;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int64_t n = nbase + j * 16 + (lane >> 4) * 4;
-                if (n >= P.N) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = sum[i][j][r] * P.alpha;
-                epilogue_store4(P, m, n, v, vec_ok);
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int64_t m = mbase + i * 16 + (lane & 15);
-        if (m >= P.M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t n = nbase + j * 16 + (lane >> 4) * 4;
-            if (n >= P.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * P.alpha;
-            epilogue_store4(P, m, n, v, vec_ok);
-        }
-    }
-}
-
-// ---- LDS-staged epilogue for full, 16-byte-aligned bf16 output tiles (wave tile 128 x 64) ------------------------------------
-// The direct epilogue above stores 8 bytes per lane: one store instruction touches 16 rows x 32 bytes, and four instructions
-// are needed to complete a 128-byte line.  Measured on the 256-tile kernels that costs ~20 us per output tile (268 MB of C at
-// 1.6 TB/s; tools/gemm_ksweep.py with and without the stores).  Here each wave passes its tile through a private 8-KiB LDS
-// region in two 64-row halves: ds_write_b64 in the accumulator layout (XOR-swizzled: chunk ^ 2*((row>>1)&7), conflict-free
-// for the 16-lane write groups), ds_read_b128 row-contiguous, then 16-byte global stores of 8 rows x 128 contiguous bytes.
-// Bias / activation / residual / accumulate are applied before the LDS write (single rounding, as in the direct epilogue).
-__device__ __forceinline__ bool epilogue_lds_ok(const GemmParams& P, int64_t m0, int64_t n0, int TM, int TN) {
-    return !P.out_f32 && P.splitk <= 1 && P.dbg_noload != 3 && (P.ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(P.C) & 15) == 0 &&
-           m0 + TM <= P.M && n0 + TN <= P.N && (P.residual == nullptr || (P.ldr & 3) == 0);
-}
-__device__ __forceinline__ bool epilogue_lds_ok(const GemmParams& P, int64_t m0, int64_t n0, int T) {
-    return epilogue_lds_ok(P, m0, n0, T, T);
-}
-// bias / per-image bias / activation for 4 consecutive outputs of a full tile
-__device__ __forceinline__ void epilogue_bias_act4(const GemmParams& P, int64_t m, int64_t n, float (&v)[4]) {
-    if (P.bias != nullptr) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)P.bias[n + r];
-    }
-    if (P.rg_bias != nullptr) {
-        const bf16* rb = P.rg_bias + (m / P.rg_rows) * P.N + n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rb[r];
-    }
-    if (P.epi == EPI_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
-    } else if (P.epi == EPI_QUICK_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = quick_gelu_f(v[r]);
-    } else if (P.epi == EPI_SILU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-    }
-}
-// wl: this wave's private 8-KiB LDS region (64 rows x 128 bytes); (mw, nw): global origin of the wave's (16 MI) x 64 tile.
-// A tile that is ADDED to the product (residual, or C itself with `accumulate`) is first brought into the same region with
-// row-contiguous 16-byte loads; each lane then folds its own 8-byte chunk in fp32 and overwrites it in place.
-template <int MI>
-__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& P, f32x4 (&acc)[MI][4], char* wl, int64_t mw, int64_t nw,
-                                                  int lane) {
-    bf16* C = reinterpret_cast<bf16*>(P.C);
-    const bool bias_act = P.bias != nullptr || P.rg_bias != nullptr || P.epi != 0;
-    // the addend staged through LDS: the residual if there is one, else C for `accumulate`
-    const bf16* pre = P.residual != nullptr ? P.residual : (P.accumulate ? C : nullptr);
-    const int64_t ldp = P.residual != nullptr ? P.ldr : P.ldc;
-    const bool pre_lds = pre != nullptr && (ldp & 7) == 0 && (reinterpret_cast<uintptr_t>(pre) & 15) == 0;
-    const bool res_direct = P.residual != nullptr && !pre_lds;            // unaligned residual: 8-byte loads in accumulator layout
-    const bool acc_direct = P.accumulate && (P.residual != nullptr || !pre_lds);
-#pragma unroll
-    for (int half = 0; half < MI / 4; ++half) {
-        if (pre_lds) {
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int row = it * 8 + (lane >> 3), p = lane & 7;
-                const bf16x8 v = ld_bf16x8(pre + (mw + half * 64 + row) * ldp + nw + p * 8);
-                *reinterpret_cast<bf16x8*>(wl + row * 128 + ((p ^ ((row >> 1) & 7)) << 4)) = v;
-            }
-        }
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = half * 4 + ii;
-            const int r = ii * 16 + (lane & 15);
-            const int sw = ((r >> 1) & 7) << 1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * P.alpha;
-                const int64_t m = mw + i * 16 + (lane & 15), n = nw + j * 16 + (lane >> 4) * 4;
-                if (bias_act) epilogue_bias_act4(P, m, n, v);
-                bf16x4* slot = reinterpret_cast<bf16x4*>(wl + r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3));
-                if (pre_lds) {
-                    const bf16x4 t = *slot;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
-                }
-                if (res_direct) {
-                    const bf16x4 t = ld_bf16x4(P.residual + m * P.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
-                }
-                if (acc_direct) {
-                    const bf16x4 t = ld_bf16x4(C + m * P.ldc + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)t[e];
-                }
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-                *slot = o;
-            }
-        }
-        // wave-private region: only this wave's own LDS traffic has to be ordered (the compiler inserts the lgkmcnt waits)
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + (lane >> 3), p = lane & 7;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(wl + row * 128 + ((p ^ ((row >> 1) & 7)) << 4));
-            st_bf16x8(C + (mw + half * 64 + row) * P.ldc + nw + p * 8, v);
-        }
-    }
-}
-
-// deterministic split-K reduction + epilogue: one thread per 4 outputs
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams P) {
-    const int64_t n4 = P.N >> 2;
-    const int64_t total = P.M * n4;
-    const bool vec_ok = ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-        const int64_t m = i / n4, n = (i % n4) * 4;
-        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < P.splitk; ++z) a += *reinterpret_cast<const f32x4*>(P.ws + ((int64_t)z * P.M + m) * P.N + n);
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = a[r] * P.alpha;
-        epilogue_store4(P, m, n, v, vec_ok);
-    }
-}
 
 // ---- kernel -------------------------------------------------------------------------------------------------------
 template <int AL, int BL, int T>
@@ -676,9 +323,6 @@ __global__ __launch_bounds__(2 * T, 2) void gemm_bf16_kernel(GemmParams P) {
 // the XOR swizzles of the images are applied to the per-lane SOURCE address (within a 128/256-byte segment: coalescing is
 // unaffected).  Tile t+1 is issued before the MFMAs of tile t into the other buffer; one vmcnt(0)+barrier per K tile.
 // Rows/columns beyond M/N are clamped (they only feed outputs that are never stored); K must be a multiple of 64.
-#define GLDS16(gptr, lptr)                                                                                             \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                           \
-                                     (__attribute__((address_space(3))) void*)(lptr), 16, 0, 0)
 
 __device__ __forceinline__ void glds_kc_tile(const bf16* base, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, char* tile,
                                              int wave, int lane) {
@@ -745,9 +389,6 @@ __device__ __forceinline__ void glds_mc_one(const bf16* base, int64_t ld, int64_
 // __builtin_amdgcn_ds_read_tr16_b64 (it cannot prove the read does not alias the DMA), which drains the prefetch of the
 // next tile right after it is issued.  The asm form is invisible to that pass; its completion is waited for explicitly
 // (tr_wait: lgkmcnt(0) naming every destination, so no consumer is scheduled above it).
-__device__ __forceinline__ uint32_t lds_addr(const char* p) {
-    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
-}
 __device__ __forceinline__ void tr_read_asm(u32x2& dst, uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
 }
@@ -758,15 +399,6 @@ __device__ __forceinline__ void frag_mc_issue(u32x2& lo, u32x2& hi, const char* 
     const int bcol = mbase * 2 + (t & 3) * 8;
     tr_read_asm(lo, lds_addr(tile + mc_off<T>(k0, bcol)));
     tr_read_asm(hi, lds_addr(tile + mc_off<T>(k0 + 4, bcol)));
-}
-__device__ __forceinline__ bf16x8 join_frag(u32x2 lo, u32x2 hi) {
-    union {
-        struct { u32x2 a, b; } s;
-        bf16x8 v;
-    } u;
-    u.s.a = lo;
-    u.s.b = hi;
-    return u.v;
 }
 template <int N>
 __device__ __forceinline__ void tr_wait(u32x2 (&lo)[N], u32x2 (&hi)[N]) {
@@ -886,50 +518,6 @@ __global__ __launch_bounds__(512, 2) void gemm_glds_kernel(GemmParams P) {
 // the first fragments of the next tile, and only then issues the last 4 MFMAs, which cover that LDS latency.
 // Every LDS read is inline asm with counted s_waitcnt lgkmcnt(n) (LDS returns in order), for two reasons: hipcc would
 // otherwise drain vmcnt before any LDS read it can see while LDS-DMA is in flight, and its scheduler clusters reads.
-template <bool MC>
-struct FragR {
-    u32x4 v;       // k-contiguous image: one ds_read_b128
-    u32x2 lo, hi;  // m-contiguous image: two ds_read_b64_tr_b16
-};
-template <bool MC, int IDX, int KK>
-__device__ __forceinline__ void fragr_issue(FragR<MC>& f, uint32_t base) {
-    if constexpr (MC) {
-        const uint32_t a = base ^ (uint32_t)(IDX << 5);  // 32-B slot (idx ^ f): bits 5..7 of the address hold f only
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.lo) : "v"(a), "n"(KK * 16384));
-        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.hi) : "v"(a), "n"(KK * 16384 + 2048));
-    } else {
-        const uint32_t a = KK ? (base ^ 64u) : base;     // chunk (4*kk + g) ^ s = (g ^ s) ^ 4*kk
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f.v) : "v"(a), "n"(IDX * 2048));
-    }
-}
-template <int N, bool MC>
-__device__ __forceinline__ void fragr_wait(FragR<MC>& f) {  // wait until at most N younger LDS operations are outstanding
-    if constexpr (MC)
-        asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(N) : "memory");
-    else
-        asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f.v) : "n"(N) : "memory");
-}
-template <bool MC>
-__device__ __forceinline__ void fragr_touch(FragR<MC>& f) {  // orders the consumers of f after the preceding wait
-    if constexpr (MC)
-        asm volatile("" : "+v"(f.lo), "+v"(f.hi));
-    else
-        asm volatile("" : "+v"(f.v));
-}
-template <bool MC>
-__device__ __forceinline__ bf16x8 fragr_value(const FragR<MC>& f) {
-    if constexpr (MC)
-        return join_frag(f.lo, f.hi);
-    else
-        return __builtin_bit_cast(bf16x8, f.v);
-}
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, N>(f);
-    }
-}
 
 // ---- implicit-GEMM gather through LDS-DMA (3x3 / 1x1 NHWC convolutions on the pipelined kernel) ----------------------
 // global_load_lds takes a per-lane source address, so the im2col gather costs nothing extra: lane (row r of the DMA group,
@@ -937,7 +525,6 @@ __device__ __forceinline__ void static_for(F&& f) {
 // rows past M) read a 16-byte zero page instead.  Requires C % 64 == 0 (a 64-deep K tile never straddles two taps): every
 // SD-2.1 / SDXL UNet and VAE conv except conv_in.  Round 3: the fused nearest-2x upsample and the transposed stride-2 gather
 // (physical pixel = logical >> 1, parity mask for the zero-stuffed grid) ride on the same per-lane source address.
-__device__ __attribute__((aligned(16))) bf16 g_zero_page[8];
 
 struct ConvDma {
     int64_t pix_off[4];   // element offset of (img, oh*stride - pad, ow*stride - pad, 0) for the lane's row in each A group;
@@ -1383,9 +970,9 @@ int launch_gemm_t(const GemmParams& P, hipStream_t stream) {
 
 // Tile choice: estimated efficiency = (useful / padded output area) x (occupied / available block slots over the rounds the
 // grid needs on 256 CUs) x relative kernel speed (128-tile 0.85, register-staged 256-tile 1.0, direct-to-LDS 256-tile 1.15).
-static inline double tile_eff(int64_t M, int64_t N, int T, double speed) {
+static inline double tile_eff(int64_t M, int64_t N, int T, double speed, int blocks_per_cu = 0) {
     const int64_t tm = cdiv64(M, T), tn = cdiv64(N, T), tiles = tm * tn;
-    const int64_t slots = 256 * (T == 128 ? 2 : 1);
+    const int64_t slots = 256 * (blocks_per_cu > 0 ? blocks_per_cu : (T == 128 ? 2 : 1));
     const int64_t rounds = cdiv64(tiles, slots);
     return ((double)M * N) / ((double)tm * tn * T * T) * ((double)tiles / (double)(rounds * slots)) * speed;
 }
@@ -1400,16 +987,51 @@ static inline double tile_cost_us(int64_t M, int64_t N, int64_t K, int TM, int T
     return (double)cdiv64(tiles, slots) * (fixed + (double)K / 64.0 * perk);
 }
 
+// The ring-buffered 128 x 128 kernel (gemm_ring.hip) replaces the register-staged 128-tile kernel wherever it is eligible: forward
+// linears and NHWC convs with K % 64 == 0 (conv: C % 64 == 0), with or without split-K (separate reduce launch only).
+template <int AL, int BL>
+static inline bool ring_ok(const GemmParams& P) {
+    if constexpr (BL != B_K || (AL != A_K && AL != A_CONV)) return false;
+    if (P.dbg_noload != 0) return false;
+    if ((P.K % BK) != 0 || P.K < BK) return false;
+    if (AL == A_CONV && (P.cv.C % BK) != 0) return false;
+    if (P.splitk > 1 && P.counters != nullptr) return false;   // the in-kernel reduction lives in the register-staged kernel
+    return true;
+}
+
 template <int AL, int BL>
 int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     if (P.M <= 0 || P.N <= 0) return DLLM_OK;
+    bool ring = ring_ok<AL, BL>(P);
+    if (P.epi == EPI_GEGLU) return ring ? dllm_launch_gemm_ring(P, AL, stream) : DLLM_ERR_SHAPE;   // only the ring kernel pairs the columns
+    if (V.force_ring && ring) return dllm_launch_gemm_ring(P, AL, stream);
+    ring = ring && V.force_tile == 0;   // tile codes 128 / 256 / 257 / 259 keep selecting the older families (tests)
     const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);
     bool glds_ok = V.use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K);
     if (AL == A_CONV)  // LDS-DMA gather: plain geometry, a K tile inside one tap, pipelined kernel only
         glds_ok = glds_ok && V.glds_pipe && (P.cv.C % BK) == 0 && BL == B_K;
-    const double e256 = tile_eff(P.M, P.N, 256, glds_ok ? 1.15 : 1.0), e128 = tile_eff(P.M, P.N, 128, 0.85);
-    const bool pick256 = e256 >= e128;
-    if (P.splitk > 1) return launch_gemm_t<AL, BL, 128>(P, stream);
+    // relative speeds: register-staged 128-tile 0.85 (two blocks per CU), ring 128-tile 1.0 (one block per CU), register-staged
+    // 256-tile 1.0, LDS-DMA 256-tile 1.15
+    const double e256 = tile_eff(P.M, P.N, 256, glds_ok ? 1.15 : 1.0);
+    const double e128 = ring ? tile_eff(P.M, P.N, 128, 1.0, 1) : tile_eff(P.M, P.N, 128, 0.85);
+    bool pick256 = e256 >= e128;
+    if (P.splitk > 1) return ring ? dllm_launch_gemm_ring(P, AL, stream) : launch_gemm_t<AL, BL, 128>(P, stream);
+    // Ring-eligible problems (forward linears, plain-geometry convs): three-way choice by estimated time = rounds of 256 blocks x
+    // (fixed + K tiles x per-K-tile cost), the per-round figures measured on the UNet's shapes at batch 2 and 16 with weights
+    // streamed from HBM (tools/unet_gemm_bench.py, profiles/r04_unet_gemm_b{2,16}.log; microseconds): ring 128 x 128: 3.2 + 0.57 k
+    // (conv gather 0.71 k); pipelined 256 x 128: 14 + 1.13 k; pipelined 256 x 256: 27 + 1.5 k.  The ring kernel wins short
+    // reductions and narrow outputs (K <= ~1000 at any size: 37 vs 65 us for [65536, 320, 320]), the 256-row tiles win deep ones.
+    int choice = 0;   // 0: the older logic below; 1 ring; 2 pipelined 256 x 128; 3 pipelined 256 x 256
+    if constexpr (BL == B_K && (AL == A_K || AL == A_CONV)) {
+        if (ring && glds_ok && V.glds_pipe && !V.force_n128) {
+            const double kt = (double)(P.K / BK);
+            const bool conv = AL == A_CONV;
+            const double t_ring = (double)cdiv64(cdiv64(P.M, 128) * cdiv64(P.N, 128), 256) * (3.2 + kt * (conv ? 0.71 : 0.57));
+            const double t_n128 = (double)cdiv64(cdiv64(P.M, 256) * cdiv64(P.N, 128), 256) * (14.0 + kt * 1.13);
+            const double t_256 = (double)cdiv64(tiles256, 256) * (27.0 + kt * 1.5);
+            choice = (t_ring <= t_n128 && t_ring <= t_256) ? 1 : (t_n128 < t_256 ? 2 : 3);
+        }
+    }
     if constexpr (!(AL == A_M && BL == B_K)) {
         int tail = 0, w = 0, blocks = 0;
         if (P.ws != nullptr && glds_ok && V.glds_pipe && V.force_tile == 0 && !V.force_n128 && P.dbg_noload == 0 &&
@@ -1436,8 +1058,10 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     }
     if constexpr (BL == B_K && (AL == A_K || AL == A_CONV)) {
         // narrow outputs (N = 320: 62 % of two 256-wide tiles, 83 % of three 128-wide ones): the pipelined kernel on 256 x 128 tiles
-        bool n128 = V.force_n128 != 0;
-        if (!n128 && V.force_tile == 0 && glds_ok && cdiv64(P.M, 256) * cdiv64(P.N, 128) >= 128) {  // at least half the CUs
+        if (choice == 1) return dllm_launch_gemm_ring(P, AL, stream);
+        if (choice == 3) pick256 = true;
+        bool n128 = V.force_n128 != 0 || choice == 2;
+        if (choice == 0 && !n128 && V.force_tile == 0 && glds_ok && cdiv64(P.M, 256) * cdiv64(P.N, 128) >= 128) {  // at least half the CUs
             const double c256 = tile_cost_us(P.M, P.N, P.K, 256, 256, 256, 9.0, 1.9);
             const double cn = tile_cost_us(P.M, P.N, P.K, 256, 128, 256, 6.0, 1.3);
             const double c128 = tile_cost_us(P.M, P.N, P.K, 128, 128, 512, 6.0, 1.75);
@@ -1516,6 +1140,7 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
         }
         return launch_gemm_t<AL, BL, 256>(P, stream);
     }
+    if (ring) return dllm_launch_gemm_ring(P, AL, stream);
     return launch_gemm_t<AL, BL, 128>(P, stream);
 }
 
@@ -1599,9 +1224,32 @@ int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || (N & 3)) return 1;
     const int64_t tiles = cdiv64(M, 128) * cdiv64(N, 128);
     const int64_t ktiles = cdiv64(K, BK);
+    if ((K % BK) == 0) {
+        // The ring-buffered kernel (one 128 x 128 block per CU, every K step overlapped with three stages of loads) needs far fewer
+        // slices than the register-staged kernel did: a slice count is worth it only when the shorter K loop pays for the fp32 slab
+        // round trip and the reduce launch.  Estimated time (us; per-round figures of launch_gemm's model, the reduce launch ~7 us,
+        // slabs written + re-read at ~4 TB/s): measured on the UNet's shapes at batch 2 (profiles/r04_unet_gemm_b2.log) this picks
+        // 1 for [8192, 320, 2880] (37 us; two slices: 51), 3 for [2048, 640, 5760] (66 -> 35), 5-6 for [512, 1280, 11520] (124 -> 39),
+        // ~20 for [128, 1280, 11520] (124 -> 24), and 1 for every K <= 1280 (a split [512, 1280, 1280] is 2-4 us SLOWER).
+        if (tiles >= 256 || ktiles < 8) return 1;
+        const double ts = 0.65;
+        int best = 1;
+        double best_t = (double)cdiv64(tiles, 256) * (3.2 + (double)ktiles * ts);
+        const int64_t smax = ktiles / 2 < 32 ? ktiles / 2 : 32;
+        for (int64_t s = 2; s <= smax; ++s) {
+            const int64_t per = cdiv64(ktiles, s);
+            if ((s - 1) * per >= ktiles) continue;   // an empty last slice: s - 1 slices do the same work
+            const double t = (double)cdiv64(tiles * s, 256) * (3.2 + (double)per * ts) + 7.0 + (double)s * (double)M * (double)N * 8.0 / 4.0e6;
+            if (t < 0.97 * best_t) {
+                best_t = t;
+                best = (int)s;
+            }
+        }
+        return best;
+    }
     if (tiles > 256 || ktiles < 16) return 1;
-    // aim at ~1.5 blocks per CU for tiny grids; grids of 128..256 tiles (one 128-tile block on half to all of the CUs, e.g. the
-    // 192-tile 3x3 convs of the UNet's first level at batch 2) are split so that two blocks share a CU: 512 slots / tiles
+    // register-staged 128-tile kernel (K % 64 != 0): aim at ~1.5 blocks per CU for tiny grids; grids of 128..256 tiles are split so
+    // that two blocks share a CU: 512 slots / tiles
     int64_t want = tiles >= 128 ? 512 / tiles : cdiv64(384, tiles);
     int64_t maxs = ktiles / 8;                  // keep >= 8 K tiles (512 k) per split
     int64_t s = want < maxs ? want : maxs;

@@ -1,0 +1,391 @@
+// Ring-buffered bf16 MFMA GEMM / implicit-GEMM convolution for SMALL GRIDS (gfx950): the UNet's layers inside the denoising loop.
+//
+// At UNet batch 2 (B_img = 1: M = 128 ... 8192 rows) a launch has 10 ... 400 output tiles and every block's K loop is exposed:
+// the register-staged 128-tile kernel (gemm.hip: gemm_bf16_kernel<.., 128>) keeps ONE K tile of global loads in flight per
+// block, so each 64-deep K step costs a full memory round trip (~1.5-2 us measured per step against 0.25 us of MFMA work:
+// profiles/r03_denoise_kernel_stats.csv, 56 % of the loop).  Little's law per CU: a 128 x 128 x 64 step consumes 32 KiB; at the
+// ~1 us latency of a loaded memory system the CU needs ~96 KiB in flight to keep its matrix pipe busy.  Hence:
+//   * 128 x 128 x 64 block tile, 8 waves as 4 (M) x 2 (N), wave tile 32 x 64 = 2 x 4 MFMA 16x16x32 tiles (two waves per SIMD:
+//     one computes while the other waits on LDS);
+//   * a RING of 4 LDS stages of 32 KiB (A 16 KiB | B 16 KiB, the k-contiguous XOR-swizzled image of the family) filled by
+//     global_load_lds_dwordx4 (LDS-DMA: no staging registers), THREE stages in flight ahead of the one being consumed; a wave
+//     issues 4 DMA instructions per stage (2 A groups + 2 B groups of 8 rows x 128 B), one before each of the K step's four
+//     MFMA groups, and waits with a COUNTED s_waitcnt vmcnt(8 / 4 / 0) -- only for the stage the next K step reads;
+//   * one raw s_barrier per K step, placed before the step's last MFMA group (whose MFMAs cover the first fragment reads of
+//     the next stage), fragment reads as inline asm with counted lgkmcnt (shared with gemm_pipe_kernel);
+//   * A operand: k-contiguous rows (nn.Linear forward) or the NHWC conv gather on the DMA's per-lane source address (3x3 / 1x1,
+//     C % 64 == 0, plain / fused nearest-2x upsample / transposed stride-2), B operand: k-contiguous weight rows;
+//   * split-K over blockIdx.y through fp32 slabs + splitk_reduce_kernel (deterministic), or a direct epilogue (bias, per-image
+//     bias, activation, residual);
+//   * EPI_GEGLU (diffusers GEGLU, ff.net.0 of BasicTransformerBlock: hidden, gate = proj(x).chunk(2); hidden * gelu(gate)):
+//     the B tile's 128 rows are re-mapped on the DMA source address so that every wave holds 32 `hidden` columns and the 32
+//     `gate` columns of the SAME outputs; the epilogue multiplies in registers and writes [M, F] -- the [M, 2F] projection never
+//     exists in memory and the element-wise launch is gone.
+// Reference call sites: the convolutions / linears of diffusers' UNet2DConditionModel as driven by
+// omni/models/dreamllm/modeling_plugins.py:806-839.
+#include "gemm_shared.h"
+
+namespace {
+
+constexpr int RING_NS = 4;                       // LDS stages
+constexpr int RING_TILE = 128 * BK * 2;          // one operand tile: 16 KiB
+constexpr int RING_STAGE = 2 * RING_TILE;        // A | B
+constexpr int RING_LDS = RING_NS * RING_STAGE;   // 128 KiB
+
+struct RingConv {
+    int64_t pix_off[2];   // element offset of (img, oh*stride - pad, ow*stride - pad, 0) of the lane's row in each of the wave's 2 A groups
+    unsigned tapmask[2];  // bit (kh*KW + kw): the tap reads inside the image (shift modes: and, for `even_only`, an even position)
+    unsigned org[2];      // shift modes: (ih0 + 2) << 16 | (iw0 + 2)
+};
+
+template <bool SHIFT>
+__device__ __forceinline__ void ring_conv_init(RingConv& d, const ConvGeom& g, int64_t m0, int64_t M, int wave, int lane) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int64_t m = m0 + (wave * 2 + q) * 8 + (lane >> 3);
+        d.pix_off[q] = 0;
+        d.tapmask[q] = 0;
+        d.org[q] = 0;
+        if (m < M) {
+            const int64_t hw = (int64_t)g.OH * g.OW;
+            const int64_t img = m / hw;
+            const int rem = (int)(m - img * hw);
+            const int oh = rem / g.OW, ow = rem - oh * g.OW;
+            const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
+            d.pix_off[q] = img * (int64_t)g.H * g.W * g.C + (SHIFT ? (int64_t)0 : ((int64_t)ih0 * g.W + iw0) * g.C);
+            if constexpr (SHIFT) d.org[q] = ((unsigned)(ih0 + 2) << 16) | (unsigned)(iw0 + 2);
+            unsigned mk = 0;
+            for (int kh = 0; kh < g.KH; ++kh)
+                for (int kw = 0; kw < g.KW; ++kw) {
+                    int ih = ih0 + kh, iw = iw0 + kw;
+                    bool ok = ih >= 0 && iw >= 0;
+                    if (SHIFT) {  // logical grid = 2x the physical one (nearest-2x upsample, or the zero-stuffed grid of a stride-2 dgrad)
+                        if (g.even_only) ok = ok && ((ih & 1) == 0) && ((iw & 1) == 0);
+                        ih >>= 1;
+                        iw >>= 1;
+                    }
+                    if (ok && ih < g.H && iw < g.W) mk |= 1u << (kh * g.KW + kw);
+                }
+            d.tapmask[q] = mk;
+        }
+    }
+}
+
+// AL: A_K (k-contiguous rows), A_CONV (plain gather), A_CONVS (shift gather).  GLU: EPI_GEGLU column pairing (P.N = F outputs).
+template <int AL, bool GLU>
+__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = 128, BN_OUT = GLU ? 64 : 128, MI = 2, NG = 2 * MI;
+    constexpr bool CONV = (AL == A_CONV || AL == A_CONVS), SHIFT = (AL == A_CONVS);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+
+    // XCD-aware grouped tile order (the hardware deals consecutive blocks to the 8 XCDs round-robin)
+    const int num_pid_m = (int)((P.M + BM - 1) / BM), num_pid_n = (int)((P.N + BN_OUT - 1) / BN_OUT);
+    const int nwg = num_pid_m * num_pid_n;
+    int wgid;
+    {
+        const int bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int pid_m, pid_n;
+    {
+        const int GROUP_M = P.group_m > 0 ? P.group_m : 8;
+        const int in_group = GROUP_M * num_pid_n;
+        const int group_id = wgid / in_group;
+        const int first_m = group_id * GROUP_M;
+        const int gsz = min(num_pid_m - first_m, GROUP_M);
+        pid_m = first_m + (wgid % in_group) % gsz;
+        pid_n = (wgid % in_group) / gsz;
+    }
+    const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN_OUT;
+
+    // this block's K tiles [kt0, kt0 + nt)
+    int kt0 = 0, nt = (int)(P.K / BK);
+    if (P.splitk > 1) {
+        const int per = (nt + P.splitk - 1) / P.splitk;
+        kt0 = blockIdx.y * per;
+        nt = max(0, min(nt - kt0, per));
+    }
+
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane DMA sources: the wave's two 8-row groups of each operand tile -------------------------------------------
+    const bf16* a_src[2];
+    const bf16* b_src[2];
+    int a_chunk[2];
+    RingConv cdma;
+    if constexpr (CONV) ring_conv_init<SHIFT>(cdma, P.cv, m0, P.M, wave, lane);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int r = (wave * 2 + q) * 8 + (lane >> 3);   // row of the 128-row tile image
+        const int c = (lane & 7) ^ ((r >> 1) & 7);        // logical 16-byte chunk held at this lane's LDS position
+        a_chunk[q] = c * 8;
+        if constexpr (!CONV) {
+            int64_t row = m0 + r;
+            row = row < P.M ? row : P.M - 1;
+            a_src[q] = P.A + row * P.lda + c * 8;
+        } else {
+            a_src[q] = P.A;
+        }
+        int64_t n;
+        if constexpr (GLU) {  // tile rows [64 w, 64 w + 32): `hidden` rows of outputs n0 + 32 w + ..; the next 32: their `gate` rows
+            const int wv = r >> 6, rr = r & 63;
+            n = n0 + wv * 32 + (rr & 31) + (rr >= 32 ? P.N : 0);
+        } else {
+            n = n0 + r;
+            n = n < P.N ? n : P.N - 1;
+        }
+        b_src[q] = P.B + n * P.ldb + c * 8;
+    }
+    // conv: tap / first channel of the NEXT stage to be issued (advanced incrementally)
+    int ctap = 0, cci = 0;
+    if constexpr (CONV) {
+        ctap = (int)(((int64_t)kt0 * BK) / P.cv.C);
+        cci = (int)(((int64_t)kt0 * BK) % P.cv.C);
+    }
+
+    // q-th DMA instruction (0, 1: A groups; 2, 3: B groups) of the stage whose K tile starts at element k0, into ring slot `slot`
+    auto issue_one = [&](int64_t k0, int slot, int q) {
+        char* st = smem + slot * RING_STAGE;
+        if (q < 2) {
+            const bf16* src;
+            if constexpr (!CONV) {
+                src = a_src[q] + k0;
+            } else {
+                const int kh = ctap / P.cv.KW, kw = ctap - kh * P.cv.KW;
+                const bool ok = (cdma.tapmask[q] >> ctap) & 1u;
+                if constexpr (SHIFT) {
+                    const int ih = ((int)(cdma.org[q] >> 16) - 2 + kh) >> 1, iw = ((int)(cdma.org[q] & 0xffffu) - 2 + kw) >> 1;
+                    src = ok ? P.A + cdma.pix_off[q] + (int64_t)((ih * P.cv.W + iw) * P.cv.C + cci + a_chunk[q]) : g_zero_page;
+                } else {
+                    src = ok ? P.A + cdma.pix_off[q] + (int64_t)((kh * P.cv.W + kw) * P.cv.C + cci + a_chunk[q]) : g_zero_page;
+                }
+            }
+            GLDS16(src, st + (wave * 2 + q) * 1024);
+        } else {
+            GLDS16(b_src[q - 2] + k0, st + RING_TILE + (wave * 2 + (q - 2)) * 1024);
+        }
+    };
+    auto conv_advance = [&]() {
+        if constexpr (CONV) {
+            cci += BK;
+            if (cci >= P.cv.C) {
+                cci -= P.cv.C;
+                ++ctap;
+            }
+        }
+    };
+
+    if (nt > 0) {
+        // ---- prologue: up to three stages in flight ------------------------------------------------------------------------
+        const int pre = nt < RING_NS - 1 ? nt : RING_NS - 1;
+        for (int s = 0; s < pre; ++s) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) issue_one((int64_t)(kt0 + s) * BK, s, q);
+            conv_advance();
+        }
+        if (pre >= 3)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (pre == 2)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        const int lg = lane >> 4, lt = lane & 15;
+        const uint32_t s0 = lds_addr(smem);
+        const uint32_t offA = (uint32_t)kc_off(wm + lt, lg);
+        const uint32_t offB = (uint32_t)RING_TILE + (uint32_t)kc_off(wn + lt, lg);
+        FragR<false> fa[2];
+        FragR<false> fb[2][4];
+        uint32_t ab = s0 + offA, bb = s0 + offB;
+        auto first_reads = [&]() {
+            static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, 0>(fb[0][decltype(j)::value], bb); });
+            fragr_issue<false, 0, 0>(fa[0], ab);
+        };
+        first_reads();
+
+        for (int t = 0; t < nt; ++t) {
+            // stage t+3 goes into the slot stage t-1 was read from: every wave finished those reads before the last barrier
+            const bool pf = t + (RING_NS - 1) < nt;
+            const int64_t kpf = (int64_t)(kt0 + t + (RING_NS - 1)) * BK;
+            const int pslot = (t + (RING_NS - 1)) & (RING_NS - 1);
+            static_for<0, NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
+                if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
+                if constexpr (g < NG - 1) {
+                    constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
+                    if constexpr (in == 0)
+                        static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, kn>(fb[kn][decltype(j)::value], bb); });
+                    fragr_issue<false, in, kn>(fa[(g + 1) & 1], ab);
+                    fragr_wait<1 + (in == 0 ? 4 : 0)>(fa[g & 1]);
+                } else {
+                    fragr_wait<0>(fa[g & 1]);
+                    if (t + 1 < nt) {
+                        // stage t+1 must have landed (this wave's share; the barrier extends that to every wave's): the stages
+                        // issued after it -- at most two -- stay in flight across the barrier
+                        const int ahead = nt - 2 - t;
+                        if (ahead >= 2)
+                            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else if (ahead == 1)
+                            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        const uint32_t so = (uint32_t)(((t + 1) & (RING_NS - 1)) * RING_STAGE);
+                        ab = s0 + offA + so;
+                        bb = s0 + offB + so;
+                        first_reads();
+                    }
+                }
+                if constexpr (i == 0) static_for<0, 4>([&](auto j) { fragr_touch(fb[kk][decltype(j)::value]); });
+                const bf16x8 va = fragr_value(fa[g & 1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (pf) conv_advance();
+        }
+    }
+
+    if constexpr (GLU) {
+        // lane holds, for rows m = m0 + wm + 16 i + (lane & 15): hidden acc[i][0..1] and gate acc[i][2..3] of the output columns
+        // n = n0 + 32 (wave & 1) + 16 j + 4 (lane >> 4) + 0..3, j = 0, 1
+        bf16* C = reinterpret_cast<bf16*>(P.C);
+        const int64_t nb = n0 + (wave & 1) * 32 + (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int64_t m = m0 + wm + i * 16 + (lane & 15);
+            if (m >= P.M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t n = nb + j * 16;
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float h = acc[i][j][e] * P.alpha, gt = acc[i][j + 2][e] * P.alpha;
+                    if (P.bias != nullptr) {
+                        h += (float)P.bias[n + e];
+                        gt += (float)P.bias[P.N + n + e];
+                    }
+                    o[e] = (bf16)(h * gelu_erf_f(gt));
+                }
+                st_bf16x4(C + m * P.ldc + n, o);
+            }
+        }
+    } else {
+        const bool staged = !P.out_f32 && P.splitk <= 1 && !P.accumulate && (P.N & 7) == 0 && (P.ldc & 7) == 0 &&
+                            (reinterpret_cast<uintptr_t>(P.C) & 15) == 0 &&
+                            (P.residual == nullptr || ((P.ldr & 7) == 0 && (reinterpret_cast<uintptr_t>(P.residual) & 15) == 0)) &&
+                            (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias) & 7) == 0) &&
+                            (P.rg_bias == nullptr || (reinterpret_cast<uintptr_t>(P.rg_bias) & 7) == 0);
+        if (!staged) {
+            gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane, blockIdx.y);
+            return;
+        }
+        // LDS-staged epilogue: the direct form stores 8 bytes per lane (one instruction = 16 rows x 32-byte pieces).  Here the wave
+        // passes its 32 x 64 tile through a private 8-KiB fp32 region of the (now idle) ring -- ds_write_b128 in the accumulator
+        // layout, 16-byte chunk c of row r at c ^ (r & 15): conflict-free for the 8-lane write groups and the 16-lane read groups
+        // -- and leaves with 16-byte stores, 8 rows x 128 contiguous bytes per instruction.  The residual is added in fp32 on the
+        // way out (row-contiguous 16-byte loads): one rounding, as in the direct epilogue.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave is done with its fragment reads: the stages are free
+        char* wl = smem + wave * 8192;
+        const int64_t mw = m0 + wm, nw = n0 + wn;
+        bf16* C = reinterpret_cast<bf16*>(P.C);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t n = nw + j * 16 + (lane >> 4) * 4;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (P.bias != nullptr && n < P.N) {
+                const bf16x4 b = ld_bf16x4(P.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[e] = (float)b[e];
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int r = i * 16 + (lane & 15);
+                const int64_t m = mw + r;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][e] * P.alpha + bv[e];
+                if (P.rg_bias != nullptr && n < P.N && m < P.M) {
+                    const bf16x4 rb = ld_bf16x4(P.rg_bias + (m / P.rg_rows) * P.N + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)rb[e];
+                }
+                if (P.epi == EPI_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf_f(v[e]);
+                } else if (P.epi == EPI_QUICK_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = quick_gelu_f(v[e]);
+                } else if (P.epi == EPI_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+                }
+                *reinterpret_cast<f32x4*>(wl + r * 256 + (((j * 4 + (lane >> 4)) ^ (r & 15)) << 4)) = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + (lane >> 3), p = lane & 7;
+            const int64_t m = mw + row, n = nw + p * 8;
+            if (m >= P.M || n >= P.N) continue;
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(wl + row * 256 + (((2 * p) ^ (row & 15)) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4*>(wl + row * 256 + (((2 * p + 1) ^ (row & 15)) << 4));
+            float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            if (P.residual != nullptr) {
+                const bf16x8 rv = ld_bf16x8(P.residual + m * P.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+            }
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
+            st_bf16x8(C + m * P.ldc + n, o);
+        }
+    }
+}
+
+template <int AL, bool GLU>
+int launch_ring_t(const GemmParams& P, hipStream_t stream) {
+    const int64_t tiles = cdiv64(P.M, 128) * cdiv64(P.N, GLU ? 64 : 128);
+    if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+    static std::atomic<uint64_t> lds_ok{0};
+    dllm_ensure_dyn_lds(&gemm_ring_kernel<AL, GLU>, RING_LDS, lds_ok);
+    const int sk = P.splitk > 1 ? P.splitk : 1;
+    hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU>), dim3((unsigned)tiles, sk), dim3(512), RING_LDS, stream, P);
+    if (sk > 1) {
+        const int64_t work = P.M * (P.N >> 2);
+        const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, P);
+    }
+    return dllm_check_launch();
+}
+
+}  // namespace
+
+// Preconditions (checked by the caller, gemm.hip: ring_ok): K % 64 == 0, K >= 64, B k-contiguous, conv: C % 64 == 0;
+// EPI_GEGLU: P.N = F with F % 64 == 0, no split-K, bf16 output, no residual / per-image bias.
+int dllm_launch_gemm_ring(const GemmParams& P, int layout_a, hipStream_t stream) {
+    if (P.epi == EPI_GEGLU) {
+        if (layout_a != A_K || P.splitk > 1 || (P.N & 63) || P.out_f32 || P.residual != nullptr || P.rg_bias != nullptr || P.accumulate)
+            return DLLM_ERR_SHAPE;
+        return launch_ring_t<A_K, true>(P, stream);
+    }
+    if (layout_a == A_K) return launch_ring_t<A_K, false>(P, stream);
+    if (layout_a == A_CONV) {
+        if (P.cv.up_shift | P.cv.even_only) return launch_ring_t<A_CONVS, false>(P, stream);
+        return launch_ring_t<A_CONV, false>(P, stream);
+    }
+    return DLLM_ERR_SHAPE;
+}

@@ -46,7 +46,7 @@ def _bf16(*ts):
             raise TypeError(f"expected bfloat16, got {t.dtype}")
 
 
-EPI = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3}
+EPI = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "silu": 3, "geglu": 4}
 
 SPLITK = True  # split-K for small grids with deep reductions (see dllm_gemm_splitk_hint)
 # Opt-in: the last K slice of a tile reduces inside the GEMM launch (no separate reduce kernel).  Correct and bit-identical to the
@@ -276,7 +276,7 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     _bf16(a, b, bias, residual)
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
-    sk = _splitk_hint(M, N, K)
+    sk = 1 if epi == "geglu" else _splitk_hint(M, N, K)
     ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
     persist = 0
     if sk == 1 and (GEMM_VARIANT & 0xffff) in (0, 259):
@@ -292,7 +292,7 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
         if gm == 0 and GEMM_TUNE_GROUP_M and 2.0 * M * N * K >= _TUNE_MIN_FLOPS:   # opt-in tool, off in the product path
             gm = _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha)
         variant = (gm << 16) | persist
-    with _GemmTimer(2.0 * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
+    with _GemmTimer((4.0 if epi == "geglu" else 2.0) * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
         check("dllm_gemm_bf16_splitk", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
               ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),
               sk, _p(ws), _p(cnt), variant, _stream())
@@ -373,6 +373,21 @@ def linear_fwd(x, w, bias=None, epi=None, residual=None, out_dtype=torch.bfloat1
     y = gemm(x2, wc, M, N, K, x2.stride(0), K, 0, 0, bias=bias, residual=r2, ldr=r2.stride(0) if r2 is not None else 0,
              epi=epi, out_dtype=out_dtype)
     return y.view(*x.shape[:-1], N)
+
+
+def linear_geglu(x, w, bias=None):
+    """diffusers GEGLU (`hidden, gate = proj(x).chunk(2, -1); hidden * gelu(gate)`, ff.net.0 of BasicTransformerBlock [ext]) as ONE
+    launch: the ring-buffered GEMM pairs the hidden / gate columns of an output inside a wave (csrc/gemm_ring.hip, EPI_GEGLU) and
+    writes [..., F] directly -- the [..., 2F] projection is never stored and the element-wise pass is gone.  Forward only (the
+    inference / denoising path); w [2F, K], bias [2F].  Shapes the kernel does not take (K % 64, F % 64) return None."""
+    x2 = _as2d(x)
+    M, K = x2.shape
+    F_ = w.shape[0] // 2
+    if K % 64 != 0 or F_ % 64 != 0 or w.shape[0] != 2 * F_ or (GEMM_VARIANT & 0xffff) not in (0, 264):
+        return None
+    wc = w if w.is_contiguous() else w.contiguous()
+    y = gemm(x2, wc, M, F_, K, x2.stride(0), K, 0, 0, bias=bias, epi="geglu")
+    return y.view(*x.shape[:-1], F_)
 
 
 def linear_dgrad(dy, w):

@@ -12,7 +12,8 @@ omni/models/dreamllm/modeling_plugins.py:375-377,556,815-821 and omni/models/dre
   -> GroupNorm+SiLU -> conv2 with bias + shortcut residual in the epilogue.  Upsample2D is fused into its conv's gather.
 * Transformer: q/k/v as ONE GEMM for self-attention, k/v of the 64 dream tokens as one GEMM (cacheable across the
   denoising loop: the context does not change between steps), flash attention head_dim 64, to_out/ff.net.2 with bias +
-  residual epilogues, GEGLU as one elementwise pass over the ff.net.0 GEMM output.
+  residual epilogues, GEGLU as one elementwise pass over the ff.net.0 GEMM output (training) or inside that GEMM's epilogue
+  (no_grad: `ops.linear_geglu`, round 4).
 """
 from __future__ import annotations
 
@@ -186,12 +187,22 @@ class Attention(nn.Module):
         return self.to_out[0](o.reshape(N, S, C), residual=residual)
 
 
+GEGLU_FUSED_MAX_ROWS = 8192
+
+
 class GEGLU(nn.Module):
     def __init__(self, dim, inner):
         super().__init__()
         self.proj = _Lin(dim, inner * 2)
 
     def forward(self, x):
+        # inference / denoising loop at small batch (M <= 8192 rows: UNet batch 2): projection + GEGLU in one launch.  At larger M the
+        # fused form's 128 x 64 output tiles re-read the activations twice as often and it only ties the two-launch path
+        # (profiles/r04_unet_gemm_b16.log: 286 vs 243 + 45 us at M = 65536).
+        if not (torch.is_grad_enabled() and x.requires_grad) and x.numel() // x.shape[-1] <= GEGLU_FUSED_MAX_ROWS:
+            y = ops.linear_geglu(x, self.proj.weight, self.proj.bias)
+            if y is not None:
+                return y
         return ops.geglu_packed(self.proj(x))  # hidden * gelu(gate); hidden, gate = chunk(2)
 
 

@@ -73,7 +73,11 @@ int dllm_groupnorm_bwd(const void* dy, const void* x, const void* gamma, const v
  * layout_a: 0 = A[m][k] k-contiguous (lda = row pitch); 1 = A stored [K][lda], m contiguous (x^T without a transpose).
  * layout_b: 0 = B given as [N][ldb] k-contiguous (nn.Linear weight [out,in]); 1 = B stored [K][ldb], n contiguous.
  *   forward y = x W^T : (0,0);  dgrad dx = dy W : (0,1);  wgrad dW = dy^T x : (1,1).
- * epi: 0 none, 1 exact-erf GELU, 2 quick-GELU (CLIP), 3 SiLU.  out_dtype DLLM_BF16 | DLLM_F32.  accumulate: C += . */
+ * epi: 0 none, 1 exact-erf GELU, 2 quick-GELU (CLIP), 3 SiLU.  out_dtype DLLM_BF16 | DLLM_F32.  accumulate: C += .
+ * epi 4 = GEGLU (diffusers `GEGLU.forward` [ext]: hidden, gate = proj(x).chunk(2, -1); hidden * gelu(gate)), forward layout (0,0)
+ *   only: B is the [2F, K] projection weight (rows [hidden F | gate F]), bias [2F] or NULL, N = F, C = [M, F] bf16; K % 64 == 0 and
+ *   F % 64 == 0, no residual / accumulate / split-K (DLLM_ERR_SHAPE otherwise).  The hidden and gate columns of an output meet
+ *   inside one wave of the ring-buffered kernel, so the [M, 2F] projection is never written. */
 int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                    int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
                    int out_dtype, int accumulate, float alpha, void* stream);
@@ -94,8 +98,10 @@ int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int la
 /* `variant` selects the kernel PER CALL (the library holds no mutable state; every entry point is re-entrant and may be called
  * from any thread on any stream): low 16 bits = tile family -- 0 automatic (what the product passes), 128 / 256 register-staged
  * tiles, 257 plain LDS-DMA 256-tile kernel, 259 software-pipelined LDS-DMA kernel (the automatic choice for eligible shapes);
- * bits 16-23 = GROUP_M of the grouped tile order (0 = per-layout default).  Tests pass 128 / 256 / 257 / 259 to cover every
- * kernel family.  Anything else returns DLLM_ERR_SHAPE.  (A build with -DDLLM_BENCH_MODES additionally accepts the
+ * 264 the ring-buffered 128 x 128 kernel for small grids (forward linears / NHWC convs with K % 64 == 0; the automatic choice
+ * wherever the register-staged 128-tile kernel used to run; ineligible calls fall back to the automatic choice);
+ * bits 16-23 = GROUP_M of the grouped tile order (0 = per-layout default).  Tests pass 128 / 256 / 257 / 259 / 262 / 264 to cover
+ * every kernel family.  Anything else returns DLLM_ERR_SHAPE.  (A build with -DDLLM_BENCH_MODES additionally accepts the
  * wrong-result diagnostic modes 258 / 260 / 263 / 265 used by tools/; the shipped library does not contain them.) */
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,

@@ -32,7 +32,7 @@ def _ops():
     (2, 8, 8, 1280, 1280, 3, "same"), (2, 16, 16, 640, 640, 3, "down"),   # small grid, deep K: split-K path
     (4, 32, 32, 128, 256, 3, "same"), (3, 24, 40, 192, 320, 3, "same"),   # full 256-tiles: LDS-DMA gather + staged epilogue
 ])
-@pytest.mark.parametrize("tile", [128, 256, 259, 262])
+@pytest.mark.parametrize("tile", [128, 256, 259, 262, 264])
 def test_conv_fwd_dgrad(N, H, W, CI, CO, K, mode, tile):
     """Implicit-GEMM NHWC conv against F.conv2d (fp32, NCHW) incl. stride-2, fused nearest-upsample, asymmetric pad,
     channel-padded conv_in / 4-channel conv_out; input gradient through the flipped-weight conv."""

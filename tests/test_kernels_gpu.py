@@ -139,7 +139,7 @@ def test_layernorm_fwd_bwd(rows, D):
 
 
 # ----------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[128, 256, 257, 259, 262])
+@pytest.fixture(params=[128, 256, 257, 259, 262, 264])
 def gemm_tile(request):
     """run the GEMM tests once per block-tile variant (128x128 / 4 waves and 256x256 / 8 waves)"""
     from dreamllm_amd import ops
@@ -681,7 +681,7 @@ def test_gemm_splitk_small_grid(M, N, K):
     assert rel_l2(dx, x.float() @ rnd(K, N, seed=1).float()) < 4e-3
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 1280, 11520), (8192, 320, 2880), (2048, 640, 5760), (104, 328, 2048)])
+@pytest.mark.parametrize("M,N,K", [(128, 1280, 11520), (512, 1280, 5120), (2048, 640, 5760), (104, 328, 2048)])
 def test_gemm_splitk_in_kernel_reduction_is_bit_identical(M, N, K):
     """The in-kernel split-K reduction (last K slice of a tile reduces, agent-scope release / acquire around a ticket) against
     the separate reduce kernel: same summation order => bit-identical, 40 launches back to back (slices of one tile run on
@@ -703,6 +703,82 @@ def test_gemm_splitk_in_kernel_reduction_is_bit_identical(M, N, K):
     torch.cuda.synchronize()
     for buf in ops._SPLITK_COUNTERS.values():
         assert int(buf.abs().sum()) == 0
+
+
+# ----------------------------------------------------------------------------- ring-buffered 128 x 128 kernel (gemm_ring.hip)
+@pytest.mark.parametrize("M,N,K", [(8192, 320, 320), (2048, 640, 640), (512, 1280, 1280), (128, 1280, 2560), (200, 328, 64),
+                                   (130, 136, 128), (257, 648, 192), (1000, 100, 256), (128, 128, 448), (8192, 2560, 320)])
+def test_gemm_ring_forward_shapes(M, N, K):
+    """The small-grid kernel (tile code 264) on the UNet's linear shapes at batch 2 and on ragged edges: K = 64 ... 2560 covers every
+    prologue / tail length of the 4-stage ring (1, 2, 3 stages in flight, then steady state), N % 8 != 0 takes the direct epilogue,
+    everything else the LDS-staged one; bias + activation + residual; fp32 output; run-to-run bit-identical (a DMA / fragment-read
+    race would show as a mismatch between repeats)."""
+    ops = _ops()
+    torch.manual_seed(M + N + K)
+    x, w, b, r = rnd(M, K), rnd(N, K, scale=0.05), rnd(N), rnd(M, N)
+    ref0 = x.float() @ w.float().t()
+    ref = F.silu(ref0 + b.float()) + r.float()
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    ops.SPLITK = False
+    try:
+        with ops.gemm_variant(264):
+            y = ops.linear_fwd(xd, wd, bias=bd, epi="silu", residual=rd)
+            assert rel_l2(y, ref) < 4e-3
+            for _ in range(10):
+                assert torch.equal(ops.linear_fwd(xd, wd, bias=bd, epi="silu", residual=rd), y)
+            y0 = ops.linear_fwd(xd, wd)
+            assert rel_l2(y0, ref0) < 4e-3
+            y32 = ops.linear_fwd(xd, wd, out_dtype=torch.float32)
+            assert rel_l2(y32, ref0) < 1e-5
+        with ops.gemm_variant(128):   # same arithmetic per output as the register-staged kernel: identical fp32 sums
+            assert rel_l2(ops.linear_fwd(xd, wd, out_dtype=torch.float32), y32.float()) < 1e-6
+    finally:
+        ops.SPLITK = True
+    # every 128 x 128 tile written exactly once
+    err = (y0.float().cpu() - ref0).abs()
+    assert float(err.max()) < 0.05 * float(ref0.abs().max()) + 0.05
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 1280, 11520), (512, 1280, 5120), (2048, 640, 5760), (104, 328, 2048), (8192, 320, 2880)])
+def test_gemm_ring_splitk(M, N, K):
+    """Split-K on the ring kernel (the automatic choice for these shapes since round 4): slabs + deterministic reduce launch."""
+    from dreamllm_amd import _lib
+    ops = _ops()
+    torch.manual_seed(M + K)
+    x, w, b, r = rnd(M, K), rnd(N, K, scale=0.02), rnd(N), rnd(M, N)
+    ref = F.gelu(x.float() @ w.float().t() + b.float()) + r.float()
+    xd, wd, bd, rd = x.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    y = ops.linear_fwd(xd, wd, bias=bd, epi="gelu", residual=rd)
+    assert rel_l2(y, ref) < 4e-3
+    for _ in range(5):
+        assert torch.equal(ops.linear_fwd(xd, wd, bias=bd, epi="gelu", residual=rd), y)
+    for sk in (2, 3, 7):   # uneven K-tile ranges, empty last slices
+        out = torch.empty(M, N, dtype=BF, device=DEV)
+        ws = torch.empty(sk * M * N, dtype=torch.float32, device=DEV)
+        _lib.check("dllm_gemm_bf16_splitk", ops._p(xd), ops._p(wd), ops._p(out), ops._p(bd), ops._p(rd), M, N, K, K, K, N, N, 0, 0,
+                   ops.EPI["gelu"], 0, 0, 1.0, sk, ops._p(ws), None, 264, ops._stream())
+        assert rel_l2(out, ref) < 4e-3, sk
+
+
+@pytest.mark.parametrize("M,K,F_", [(512, 1280, 5120), (8192, 320, 1280), (100, 320, 1280), (2048, 640, 2560), (128, 64, 64)])
+def test_gemm_ring_geglu_epilogue(M, K, F_):
+    """diffusers GEGLU fused into the projection (EPI_GEGLU): out = (x Wh^T + bh) * gelu(x Wg^T + bg), against fp32 torch and against
+    the two-launch path (GEMM + element-wise GEGLU), with and without bias."""
+    ops = _ops()
+    torch.manual_seed(M + F_)
+    x, w, b = rnd(M, K), rnd(2 * F_, K, scale=0.05), rnd(2 * F_)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    z = x.float() @ w.float().t() + b.float()
+    ref = z[:, :F_] * F.gelu(z[:, F_:])
+    y = ops.linear_geglu(xd, wd, bd)
+    assert y is not None and y.shape == (M, F_)
+    assert rel_l2(y, ref) < 4e-3
+    two = ops.geglu_packed(ops.linear_fwd(xd, wd, bias=bd))
+    assert rel_l2(y, two.float()) < 6e-3          # the two-launch path rounds the projection to bf16 first
+    z0 = x.float() @ w.float().t()
+    assert rel_l2(ops.linear_geglu(xd, wd, None), z0[:, :F_] * F.gelu(z0[:, F_:])) < 4e-3
+    assert torch.equal(ops.linear_geglu(xd, wd, bd), y)
+    assert ops.linear_geglu(rnd(8, 72).to(DEV), rnd(128, 72).to(DEV)) is None   # K % 64 != 0: caller falls back
 
 
 # ----------------------------------------------------------------------------- greedy-decode kernels
