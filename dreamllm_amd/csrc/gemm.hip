@@ -942,7 +942,9 @@ static inline bool streamk_plan(int64_t M, int64_t N, int64_t K, int& full, int&
 static inline bool streamk_plan_small(int64_t M, int64_t N, int64_t K, int& tail, int& w, int& blocks) {
     const int64_t tiles = cdiv64(M, 256) * cdiv64(N, 256);
     const int64_t nt = K / BK;
-    if (tiles < 48 || tiles > 208 || nt < 96 || (K % BK) != 0) return false;
+    // N >= 512: at N = 320 (the UNet's first level) the 256-wide tiles waste 37 % of their columns and the fix-up launch alone costs
+    // 60 us; the ring kernel runs [8192, 320, 8640] in 97 us against 140 us for this path (profiles/r04_denoise_kernel_stats.csv)
+    if (tiles < 48 || tiles > 208 || nt < 96 || (K % BK) != 0 || N < 512) return false;
     const int64_t total = tiles * nt;
     w = (int)cdiv64(total, 256);
     if (w < 32) return false;
