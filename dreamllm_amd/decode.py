@@ -7,7 +7,9 @@ stream.  Here the token step is a fixed sequence of launches on static buffers:
 
     embed[tok] -> 32 x { [RMSNorm + q/k/v GEMV] -> [RoPE(pos on device) + K/V append to the cache at pos] -> decode attention
     over the cache (valid length on device) -> [o GEMV + residual] -> [RMSNorm + gate/up GEMV + SwiGLU] -> [down GEMV + residual] }
-    -> [final RMSNorm + lm_head GEMV] (fp32 logits) -> argmax -> pos/len/step += 1      ([..] = one launch; 7 per layer)
+    -> [final RMSNorm + lm_head GEMV] (fp32 logits) -> argmax -> pos/len/step += 1      ([..] = one launch; 7 per layer;
+    round 4: RoPE + append folded into the attention launch -> 6 per layer; the split-KV merge can be folded in
+    too (`fuse_combine=True`: 5 per layer) but measured 1 % slower than the separate combine launch)
 
 captured once per (batch, max_len) in a hipGraph (`torch.cuda.CUDAGraph`) and replayed per token; nothing in it depends on the
 host.  Prefill runs through the normal model forward (MFMA GEMMs + flash attention) and its K/V are copied into the cache.
@@ -23,13 +25,17 @@ from . import ops
 
 class GreedyDecodeSession:
     def __init__(self, model, batch_size: int, max_len: int, use_graph: bool = True, nsplit: int = 8, fused: bool = True,
-                 vocab_limit: int | None = 32000):
+                 vocab_limit: int | None = 32000, fuse_rope: bool = True, fuse_combine: bool = False):
         """`vocab_limit`: argmax runs over `logits[..., :vocab_limit]` -- the reference loop slices `[..., :32000]`
         (omni/eval/language_eval/modeling_dreamllm.py:79,86) so that none of the added special tokens (<dream_start>, <im_*>,
         [PAD] ...) can be emitted; None = whole vocabulary."""
         cfg = model.config
         self.model = model
         self.B, self.max_len, self.use_graph, self.nsplit, self.fused = batch_size, max_len, use_graph, nsplit, fused
+        self.fuse_rope = fuse_rope
+        # arrival counters of the in-launch split-KV merge (zero at rest; one array per session = per stream in flight)
+        self.attn_counters = (torch.zeros(batch_size * cfg.num_attention_heads, dtype=torch.int32, device=model.device)
+                              if fuse_combine else None)
         if batch_size > 8:
             raise ValueError("the decode GEMV handles up to 8 sequences per step")
         dev, dt = model.device, model.dtype
@@ -71,10 +77,15 @@ class GreedyDecodeSession:
                 q, k, v = ops.gemv_fused(x, (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight),
                                          norm_w=layer.input_layernorm.weight, eps=eps)
                 q = q.view(B, H, D)
-                ops.rope_append_(q, k.view(B, Hkv, D), v.view(B, Hkv, D), self.kc[li], self.vc[li], self.cos, self.sin, pos,
-                                 kv_len=self.kv_len)
-                o = ops.attn_decode(q, self.kc[li], self.vc[li], self.kv_len, 1.0 / math.sqrt(D), self.nsplit,
-                                    kv_start=self.kv_start)
+                if self.fuse_rope:   # RoPE + cache append inside the attention launch (round 4)
+                    o = ops.attn_decode_rope(q, k.view(B, Hkv, D), v.view(B, Hkv, D), self.kc[li], self.vc[li], self.kv_len, self.cos,
+                                             self.sin, pos, 1.0 / math.sqrt(D), self.nsplit, kv_start=self.kv_start,
+                                             counters=self.attn_counters)
+                else:
+                    ops.rope_append_(q, k.view(B, Hkv, D), v.view(B, Hkv, D), self.kc[li], self.vc[li], self.cos, self.sin, pos,
+                                     kv_len=self.kv_len)
+                    o = ops.attn_decode(q, self.kc[li], self.vc[li], self.kv_len, 1.0 / math.sqrt(D), self.nsplit,
+                                        kv_start=self.kv_start)
                 x2 = ops.gemv(o.view(B, H * D), at.o_proj.weight, residual=x)
                 act = ops.gemv_fused(x2, (mlp.gate_proj.weight, mlp.up_proj.weight), norm_w=layer.post_attention_layernorm.weight,
                                      eps=eps, swiglu=True)

@@ -1407,6 +1407,31 @@ def attn_decode(q, kcache, vcache, kv_len, scale=None, nsplit=8, out=None, kv_st
     return out
 
 
+def attn_decode_rope(q, k_new, v_new, kcache, vcache, kv_len, cos, sin, pos, scale=None, nsplit=8, out=None, kv_start=None,
+                     counters=None):
+    """`rope_append_` + `attn_decode` in one launch pair: q [B,H,D] UN-rotated (left untouched), k_new / v_new [B,Hkv,D] the step's
+    key / value (k un-rotated); the kernel rotates q in registers, writes rotate(k_new) and v_new to cache slot kv_len[b] - 1 and
+    attends to them in the same launch.  pos int64 [B] and kv_len int32 [B] on device.  `counters` (int32 [B*H], zero at rest): the
+    last split to finish merges the partial states inside the launch instead of a combine launch."""
+    _need_gpu(q, k_new, v_new, kcache, vcache, kv_len, cos, sin, pos)
+    _bf16(q, k_new, v_new, kcache, vcache)
+    B, H, D = q.shape
+    Hkv = kcache.shape[2]
+    if kcache.stride() != vcache.stride() or kcache.stride(3) != 1 or q.stride(2) != 1:
+        raise ValueError("attn_decode_rope: k/v caches must share strides; head dim contiguous")
+    if not (k_new.is_contiguous() and v_new.is_contiguous()) or k_new.shape != (B, Hkv, D) or v_new.shape != (B, Hkv, D):
+        raise ValueError("attn_decode_rope: contiguous k_new / v_new of shape [B, Hkv, D] required")
+    if kv_len.dtype != torch.int32 or pos.dtype != torch.int64:
+        raise TypeError("attn_decode_rope: kv_len must be int32, pos int64")
+    if out is None:
+        out = torch.empty(B, H, D, dtype=q.dtype, device=q.device)
+    ws = torch.empty(_lib.lib().dllm_attn_decode_ws_floats(B, H, D, nsplit), dtype=torch.float32, device=q.device)
+    check("dllm_attn_decode_rope", _p(q), _p(k_new), _p(v_new), _p(kcache), _p(vcache), _p(cos), _p(sin), _p(pos.reshape(-1)), _p(kv_len),
+          _p(kv_start), _p(out), _p(ws), _p(counters), B, H, Hkv, D, q.stride(0), q.stride(1), k_new.stride(0), kcache.stride(0), kcache.stride(1),
+          kcache.stride(2), out.stride(0), out.stride(1), float(scale if scale is not None else D ** -0.5), nsplit, _stream())
+    return out
+
+
 # --------------------------------------------------------------------------------------------- torch.compile coexistence
 _DYNAMO_OPAQUE = False
 

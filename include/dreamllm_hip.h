@@ -204,7 +204,8 @@ int dllm_cfg_ddim_step(const void* pred, float* latents, void* next_in, int64_t 
 /* ---------------------------------------------------------------------------------------------------- greedy decode
  * Token step of the KV-cache decode loop (omni/eval/language_eval/modeling_dreamllm.py:76-97): every nn.Linear of
  * modeling_dreamllm.py:212-239,254-400,1452 degenerates to y[M<=8][N] = x W^T, HBM-bound on W.
- * dllm_gemv_bf16: one wave per output row, fp32 accumulate, optional fused residual, bf16 or fp32 (logits) output.
+ * dllm_gemv_bf16: fp32 accumulate, optional fused residual, bf16 or fp32 (logits) output.  M <= 4 with M * K * 2 <= 60 KiB: x staged
+ * once per block in LDS, two output rows per wave, v_dot2c_f32_bf16 (round 4); otherwise one wave per output row.
  * dllm_attn_decode: softmax(q K^T * scale) V for ONE query token per (b, h) over the cache [B][S_max][Hkv][D]; the valid
  * length kv_len[b] is read from device memory so that the launch is step-invariant (hipGraph replay).  ws: fp32 workspace of
  * dllm_attn_decode_ws_floats(B, H, D, nsplit) elements (split-KV partial softmax states).  kv_start (int32 [B] on device, or
@@ -224,6 +225,18 @@ int64_t dllm_attn_decode_ws_floats(int B, int H, int D, int nsplit);
 int dllm_attn_decode(const void* q, const void* kcache, const void* vcache, const int* kv_len, const int* kv_start, void* out,
                      float* ws, int B, int H, int Hkv, int D, int64_t q_sb, int64_t q_sh, int64_t c_sb, int64_t c_ss, int64_t c_sh, int64_t o_sb,
                      int64_t o_sh, float scale, int nsplit, void* stream);
+/* dllm_rope_append + dllm_attn_decode in ONE launch pair (round 4; 6 launches per layer and token instead of 7): q [B][H][D]
+ * UN-rotated (read only), k_new / v_new [B][Hkv][D] (batch pitch kv_sb, k un-rotated) = the step's key / value.  The attention
+ * kernel rotates q in registers (rounded to bf16 as dllm_rope_append stores it), rotates k_new with rotary position pos[b], writes
+ * it and v_new to cache slot kv_len[b] - 1 and attends to them in the same launch (apply_rotary_pos_emb
+ * modeling_dreamllm.py:184-209 + the cache update :340-345 + the 1-token attention :346-400).  counters: int32 [B * H], all zero
+ * on entry and left all zero, or NULL: with counters the split that finishes last merges the split-KV partial states inside the
+ * launch (agent-scope stores / loads around a ticket; fixed split order = the combine kernel's bits), so the combine launch
+ * disappears too: 5 launches per layer and token. */
+int dllm_attn_decode_rope(const void* q, const void* k_new, const void* v_new, void* kcache, void* vcache, const float* cos_tab,
+                          const float* sin_tab, const int64_t* pos, const int* kv_len, const int* kv_start, void* out, float* ws,
+                          int* counters, int B, int H, int Hkv, int D, int64_t q_sb, int64_t q_sh, int64_t kv_sb, int64_t c_sb,
+                          int64_t c_ss, int64_t c_sh, int64_t o_sb, int64_t o_sh, float scale, int nsplit, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------- test probes
  * hardware-convention probes used by tests/test_kernels_gpu.py (ds_read_b64_tr_b16 and MFMA 16x16x32 fragment layouts) */

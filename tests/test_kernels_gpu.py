@@ -782,7 +782,8 @@ def test_gemm_ring_geglu_epilogue(M, K, F_):
 
 
 # ----------------------------------------------------------------------------- greedy-decode kernels
-@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (1, 11008, 4096), (3, 1000, 11008), (8, 515, 128), (2, 32008, 512)])
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (1, 11008, 4096), (3, 1000, 11008), (8, 515, 128), (2, 32008, 512), (1, 4096, 11008),
+                                   (1, 1001, 2048), (4, 37, 6152), (2, 12, 8)])
 @pytest.mark.parametrize("f32", [False, True])
 def test_gemv(M, N, K, f32):
     ops = _ops()
@@ -850,6 +851,46 @@ def test_gemv_fused_norm_multi_swiglu_and_rope_append():
     for b in range(B):
         assert torch.equal(kc[b, pos[b]], k_ref[b, 0]) and torch.equal(vc[b, pos[b]], vv[b])
     assert int((kc != 0).any(dim=-1).any(dim=-1).sum()) == B  # exactly one cache row per batch element written
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,Smax,lens,starts,nsplit", [
+    (1, 32, 32, 128, 640, [515], None, 8), (3, 8, 2, 128, 96, [1, 96, 57], None, 8), (2, 6, 6, 64, 64, [64, 13], [3, 0], 4),
+    (2, 4, 4, 128, 40, [5, 40], [2, 30], 1)])
+def test_attn_decode_rope_fused_matches_rope_append_then_attn_decode(B, H, Hkv, D, Smax, lens, starts, nsplit):
+    """RoPE + KV-cache append folded into the decode-attention launch (dllm_attn_decode_rope) against the two launches it replaces,
+    on the same inputs: attention output, the appended cache rows (rotated k, v) and every other cache row untouched; grouped-query
+    heads, left-padded prompts (kv_start), the new token alone in the cache (len 1), nsplit 1."""
+    ops = _ops()
+    torch.manual_seed(B * 7 + H)
+    q, kn, vn = rnd(B, H, D, seed=B + H).to(DEV), rnd(B, Hkv, D).to(DEV), rnd(B, Hkv, D).to(DEV)
+    kc0, vc0 = rnd(B, Smax, Hkv, D).to(DEV), rnd(B, Smax, Hkv, D).to(DEV)
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    ang = torch.arange(Smax + 8).float()[:, None] * inv[None]
+    cos, sin = ang.cos().to(DEV), ang.sin().to(DEV)
+    kv_len = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    kv_start = None if starts is None else torch.tensor(starts, dtype=torch.int32, device=DEV)
+    # rotary position = the row's own token count - 1 (left padding: slot and position differ)
+    pos = torch.tensor([n - 1 - (0 if starts is None else starts[b]) for b, n in enumerate(lens)], dtype=torch.int64, device=DEV)
+    kc1, vc1, q1 = kc0.clone(), vc0.clone(), q.clone()
+    ops.rope_append_(q1, kn, vn, kc1, vc1, cos, sin, pos, kv_len=kv_len)
+    ref = ops.attn_decode(q1, kc1, vc1, kv_len, nsplit=nsplit, kv_start=kv_start)
+    kc2, vc2, q2 = kc0.clone(), vc0.clone(), q.clone()
+    out = ops.attn_decode_rope(q2, kn, vn, kc2, vc2, kv_len, cos, sin, pos, nsplit=nsplit, kv_start=kv_start)
+    assert torch.equal(q2, q)                                   # q is read only
+    # the in-launch merge of the split-KV states (no combine launch): same bits as the combine kernel, 30 launches back to back
+    # (a stale cross-XCD read would show as a mismatch), counters back at zero
+    cnt = torch.zeros(B * H, dtype=torch.int32, device=DEV)
+    for it in range(30):
+        kc3, vc3 = kc0.clone(), vc0.clone()
+        o3 = ops.attn_decode_rope(q2, kn, vn, kc3, vc3, kv_len, cos, sin, pos, nsplit=nsplit, kv_start=kv_start, counters=cnt)
+        assert torch.equal(o3, out), it
+    assert int(cnt.abs().sum()) == 0 and torch.equal(kc3, kc2) and torch.equal(vc3, vc2)
+    assert rel_l2(out, ref.float()) < 2e-3
+    assert rel_l2(kc2, kc1.float()) < 1e-3 and torch.equal(vc2, vc1)
+    same = (kc2 == kc1).all(dim=-1).all(dim=-1)                 # [B, Smax]: only the appended row may differ (by fp32 contraction order)
+    for b, n in enumerate(lens):
+        assert bool(same[b, : n - 1].all()) and bool(same[b, n:].all())
+        assert rel_l2(kc2[b, n - 1], kc1[b, n - 1].float()) < 4e-3
 
 
 @pytest.mark.parametrize("V", [1000, 1001])
