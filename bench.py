@@ -371,6 +371,8 @@ def main():
             "loss": train.get("loss"),
             "roofline": train.get("roofline"),
             "e2e_frac_mfma_peak": train.get("e2e_frac_mfma_peak"),
+            "e2e_frac_mfma_peak_full_lm_head": train.get("e2e_frac_mfma_peak_full_lm_head"),
+            "flops_per_sample": train.get("flops_per_sample"),
             "peak_hbm_gb": train.get("peak_hbm_gb"),
             # ranks an all-reduce on backend nccl (= RCCL) actually summed over; DDP's per-bucket timeline of rank 0 (N > 1):
             # comm_exposed_ms = last all-reduce done - last bucket ready = communication the backward did not hide

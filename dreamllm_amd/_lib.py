@@ -53,6 +53,8 @@ SIGNATURES = {
     "dllm_softmax_rows": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_void_p],
     "dllm_adamw": [c_void_p] * 4 + [c_i64, c_int, c_int] + [c_float] * 5 + [c_int, c_float, c_void_p, c_void_p],
     "dllm_sumsq": [c_void_p, c_i64, c_int, c_void_p, c_void_p],
+    "dllm_adamw_multi": [c_void_p] * 5 + [c_int] + [c_float] * 5 + [c_int, c_float, c_void_p, c_void_p],
+    "dllm_sumsq_multi": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "dllm_reduce_sum_f32": [c_void_p, c_i64, c_void_p, c_void_p],
     "dllm_mse_sum": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p],
     "dllm_mse_bwd": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
@@ -67,6 +69,7 @@ SIGNATURES = {
 # functions whose return type is not int
 RESTYPES = {"dllm_groupnorm_ws_floats": (c_i64, [c_int, c_int, c_int]),
             "dllm_gemm_streamk_ws_bytes": (c_i64, []),
+            "dllm_sumsq_multi_parts": (c_i64, [c_void_p, c_int]),
             "dllm_attn_decode_ws_floats": (c_i64, [c_int, c_int, c_int, c_int])}
 
 _lib = None

@@ -341,6 +341,92 @@ __global__ __launch_bounds__(256) void adamw_vec8_kernel(bf16* __restrict__ p, c
     }
 }
 
+// ---- multi-tensor forms (round 4): the 7B step ran 295 AdamW + 295 sum-of-squares launches (one per parameter tensor) ------------
+// One launch serves up to MT_MAX tensors: the table of pointers / sizes travels as a kernel argument (no device-side table, no
+// host-to-device copy), block b owns chunk b of the concatenated chunk space (MT_CHUNK elements of ONE tensor per chunk), found by
+// a scan of the table's chunk prefix.  Same arithmetic, element for element, as adamw_vec8_kernel / sumsq_kernel's per-element
+// terms; the sum-of-squares partial of a chunk is a fixed-order block reduction, one float per chunk, summed later in chunk order
+// (dllm_reduce_sum_f32): deterministic, identical on every data-parallel replica.
+constexpr int MT_MAX = 48;
+constexpr int MT_CHUNK = 256 * 8 * 16;   // elements per block: 16 vectors of 8 per thread (458 KiB of AdamW traffic)
+struct MtAdamTable {
+    bf16* p[MT_MAX];
+    const bf16* g[MT_MAX];
+    bf16* m[MT_MAX];
+    bf16* v[MT_MAX];
+    int64_t n8[MT_MAX];         // vectors of 8 elements
+    int chunk_end[MT_MAX];      // exclusive prefix end of each tensor's chunks inside this launch
+    int count;
+};
+struct MtSumsqTable {
+    const bf16* x[MT_MAX];
+    int64_t n8[MT_MAX];
+    int chunk_end[MT_MAX];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(MtAdamTable T, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                          float bc2, float gscale, const float* __restrict__ gscale_dev) {
+    int t = 0;
+    while (t < T.count - 1 && (int)blockIdx.x >= T.chunk_end[t]) ++t;
+    const int c0 = t == 0 ? 0 : T.chunk_end[t - 1];
+    const int64_t base = (int64_t)((int)blockIdx.x - c0) * (MT_CHUNK / 8);
+    const int64_t n8 = T.n8[t];
+    if (gscale_dev != nullptr) gscale *= gscale_dev[0];
+    const float decay = 1.f - lr * wd;
+    bf16x8* pv = reinterpret_cast<bf16x8*>(T.p[t]);
+    const bf16x8* gv = reinterpret_cast<const bf16x8*>(T.g[t]);
+    bf16x8* mv = reinterpret_cast<bf16x8*>(T.m[t]);
+    bf16x8* vv = reinterpret_cast<bf16x8*>(T.v[t]);
+    const int64_t end = min(n8, base + MT_CHUNK / 8);
+    for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+        bf16x8 P = __builtin_nontemporal_load(pv + i);
+        const bf16x8 G = __builtin_nontemporal_load(gv + i);
+        bf16x8 M = __builtin_nontemporal_load(mv + i), V = __builtin_nontemporal_load(vv + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float pf = (float)P[e];
+            const float gf = (float)G[e] * gscale;
+            float mf = (float)M[e], vf = (float)V[e];
+            pf *= decay;
+            mf = b1 * mf + (1.f - b1) * gf;
+            vf = b2 * vf + (1.f - b2) * gf * gf;
+            const float denom = sqrtf(vf) / sqrtf(bc2) + eps;
+            pf -= (lr / bc1) * mf / denom;
+            P[e] = (bf16)pf;
+            M[e] = (bf16)mf;
+            V[e] = (bf16)vf;
+        }
+        __builtin_nontemporal_store(P, pv + i);
+        __builtin_nontemporal_store(M, mv + i);
+        __builtin_nontemporal_store(V, vv + i);
+    }
+}
+
+__global__ __launch_bounds__(256) void sumsq_multi_kernel(MtSumsqTable T, float* __restrict__ partials) {
+    __shared__ float scratch[4];
+    int t = 0;
+    while (t < T.count - 1 && (int)blockIdx.x >= T.chunk_end[t]) ++t;
+    const int c0 = t == 0 ? 0 : T.chunk_end[t - 1];
+    const int64_t base = (int64_t)((int)blockIdx.x - c0) * (MT_CHUNK / 8);
+    const int64_t end = min(T.n8[t], base + MT_CHUNK / 8);
+    const bf16x8* xv = reinterpret_cast<const bf16x8*>(T.x[t]);
+    float s = 0.f;
+    for (int64_t i = base + threadIdx.x; i < end; i += 1024) {   // four 16-byte loads in flight per thread
+        bf16x8 a = xv[i], b = zero_bf16x8(), c = zero_bf16x8(), d = zero_bf16x8();
+        if (i + 256 < end) b = xv[i + 256];
+        if (i + 512 < end) c = xv[i + 512];
+        if (i + 768 < end) d = xv[i + 768];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float fa = (float)a[e], fb = (float)b[e], fc = (float)c[e], fd = (float)d[e];
+            s += fa * fa + fb * fb + fc * fc + fd * fd;
+        }
+    }
+    s = block_sum<4>(s, scratch);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
+}
+
 // sum of squares of a bf16/fp32 buffer (grad-norm clipping) as one partial per block: no atomics => bit-identical on every
 // DDP replica.  HBM-bound (2 B/elt): 1024-thread blocks, 16-byte loads, 4 of them in flight per thread (64 KiB per CU).
 template <typename T>
@@ -665,6 +751,77 @@ int dllm_sumsq(const void* x, int64_t n, int dtype, float* out, void* stream) {
         hipLaunchKernelGGL(sumsq_kernel<float>, dim3((unsigned)g), dim3(1024), 0, (hipStream_t)stream, (const float*)x, n, out);
     else
         return DLLM_ERR_DTYPE;
+    return dllm_check_launch();
+}
+
+// Multi-tensor AdamW: `count` bf16 parameter tensors with bf16 moments sharing every hyper-parameter and the step number, each
+// 16-byte aligned with n[i] % 8 == 0 (every weight matrix; callers send the rest through dllm_adamw).  p / g / m / v / n are HOST
+// arrays of `count` entries; the library issues ceil(count / 48) launches (7 for the 295 trainable tensors of the 7B stage-II step,
+// instead of 295).  Same update, element for element, as dllm_adamw.
+int dllm_adamw_multi(void* const* p, const void* const* g, void* const* m, void* const* v, const int64_t* n, int count, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                     const float* grad_scale_dev, void* stream) {
+    if (count < 0 || step < 1) return DLLM_ERR_SHAPE;
+    if (count == 0) return DLLM_OK;
+    if (p == nullptr || g == nullptr || m == nullptr || v == nullptr || n == nullptr) return DLLM_ERR_SHAPE;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    for (int i = 0; i < count; ++i) {
+        if (n[i] < 0 || (n[i] & 7)) return DLLM_ERR_ALIGN;
+        if ((reinterpret_cast<uintptr_t>(p[i]) | reinterpret_cast<uintptr_t>(g[i]) | reinterpret_cast<uintptr_t>(m[i]) |
+             reinterpret_cast<uintptr_t>(v[i])) & 15)
+            return DLLM_ERR_ALIGN;
+    }
+    for (int i0 = 0; i0 < count; i0 += MT_MAX) {
+        MtAdamTable T{};
+        int chunks = 0, k = 0;
+        for (int i = i0; i < count && k < MT_MAX; ++i) {
+            if (n[i] == 0) continue;
+            T.p[k] = (bf16*)p[i]; T.g[k] = (const bf16*)g[i]; T.m[k] = (bf16*)m[i]; T.v[k] = (bf16*)v[i];
+            T.n8[k] = n[i] / 8;
+            chunks += (int)cdiv64(n[i], MT_CHUNK);
+            T.chunk_end[k] = chunks;
+            ++k;
+        }
+        T.count = k;
+        if (k == 0) continue;
+        hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, T, lr, beta1, beta2, eps,
+                           weight_decay, bc1, bc2, grad_scale, grad_scale_dev);
+    }
+    return dllm_check_launch();
+}
+
+// chunks (= partial sums) dllm_sumsq_multi writes for these sizes
+int64_t dllm_sumsq_multi_parts(const int64_t* n, int count) {
+    int64_t c = 0;
+    for (int i = 0; i < count; ++i) c += cdiv64(n[i] > 0 ? n[i] : 0, MT_CHUNK);
+    return c;
+}
+
+// Sum of squares of `count` bf16 tensors (16-byte aligned, n[i] % 8 == 0): one fp32 partial per chunk of 32768 elements into
+// partials[0 .. dllm_sumsq_multi_parts), in tensor-then-chunk order; ceil(count / 48) launches.  Combine with dllm_reduce_sum_f32.
+int dllm_sumsq_multi(const void* const* x, const int64_t* n, int count, float* partials, void* stream) {
+    if (count < 0) return DLLM_ERR_SHAPE;
+    if (count == 0) return DLLM_OK;
+    if (x == nullptr || n == nullptr || partials == nullptr) return DLLM_ERR_SHAPE;
+    for (int i = 0; i < count; ++i)
+        if (n[i] < 0 || (n[i] & 7) || (reinterpret_cast<uintptr_t>(x[i]) & 15)) return DLLM_ERR_ALIGN;
+    int64_t done = 0;
+    for (int i0 = 0; i0 < count; i0 += MT_MAX) {
+        MtSumsqTable T{};
+        int chunks = 0, k = 0;
+        for (int i = i0; i < count && k < MT_MAX; ++i) {
+            if (n[i] == 0) continue;
+            T.x[k] = (const bf16*)x[i];
+            T.n8[k] = n[i] / 8;
+            chunks += (int)cdiv64(n[i], MT_CHUNK);
+            T.chunk_end[k] = chunks;
+            ++k;
+        }
+        T.count = k;
+        if (k == 0) continue;
+        hipLaunchKernelGGL(sumsq_multi_kernel, dim3((unsigned)chunks), dim3(256), 0, (hipStream_t)stream, T, partials + done);
+        done += chunks;
+    }
     return dllm_check_launch();
 }
 

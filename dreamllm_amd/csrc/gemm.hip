@@ -36,22 +36,26 @@ struct Variant {
     int force_n128 = 0;  // tile code 262: the 256 x 128 pipelined kernel wherever it is eligible (tests)
     int persist = 0;     // bit 24: XCD-synchronised persistent walk of the pipelined 256-tile kernel (needs the workspace)
     int force_ring = 0;  // tile code 264: the 128 x 128 ring-buffered kernel (gemm_ring.hip) wherever it is eligible (tests, tools)
+    int no_ring = 0;     // bit 25: never pick the ring-buffered kernel by itself (the round-3 selection: A/B knob of tools / bench)
+    int force_mfma32 = 0;  // tile code 266: the MFMA 32x32x16 experiment (gemm_mfma32.hip) wherever it is eligible (tools)
 };
 static inline int parse_variant(int variant, Variant& v) {
     const int tile = variant & 0xffff;
     v.group_m = (variant >> 16) & 0xff;
-    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262 || tile == 264;
+    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262 || tile == 264 || tile == 266;
 #ifdef DLLM_BENCH_MODES
     ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265;
     v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
 #endif
-    if (!ok || (variant >> 25) != 0) return DLLM_ERR_SHAPE;
+    if (!ok || (variant >> 26) != 0) return DLLM_ERR_SHAPE;
+    v.no_ring = (variant >> 25) & 1;
     v.persist = (variant >> 24) & 1;
     v.use_glds = (tile == 0 || tile >= 257);
     v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 262 || tile == 263 || tile == 265);
     v.force_tile = tile >= 257 ? 256 : tile;
     v.force_n128 = tile == 262;
     v.force_ring = tile == 264;
+    v.force_mfma32 = tile == 266;
     if (v.force_ring) v.force_tile = 0;
     return DLLM_OK;
 }
@@ -1007,7 +1011,13 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     bool ring = ring_ok<AL, BL>(P);
     if (P.epi == EPI_GEGLU) return ring ? dllm_launch_gemm_ring(P, AL, stream) : DLLM_ERR_SHAPE;   // only the ring kernel pairs the columns
     if (V.force_ring && ring) return dllm_launch_gemm_ring(P, AL, stream);
-    ring = ring && V.force_tile == 0;   // tile codes 128 / 256 / 257 / 259 keep selecting the older families (tests)
+    if constexpr (AL == A_K && BL == B_K) {
+        if (V.force_mfma32 && (P.M % 256) == 0 && (P.N % 256) == 0 && (P.K % BK) == 0 && P.K >= BK && !P.out_f32 && P.bias == nullptr &&
+            P.residual == nullptr && P.rg_bias == nullptr && P.epi == 0 && !P.accumulate && P.splitk <= 1 && (P.ldc & 7) == 0 &&
+            (reinterpret_cast<uintptr_t>(P.C) & 15) == 0)
+            return dllm_launch_gemm_pipe32(P, stream);
+    }
+    ring = ring && V.force_tile == 0 && !V.no_ring;   // tile codes 128 / 256 / 257 / 259 keep selecting the older families (tests)
     const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);
     bool glds_ok = V.use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K);
     if (AL == A_CONV)  // LDS-DMA gather: plain geometry, a K tile inside one tap, pipelined kernel only
@@ -1025,7 +1035,9 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     // reductions and narrow outputs (K <= ~1000 at any size: 37 vs 65 us for [65536, 320, 320]), the 256-row tiles win deep ones.
     int choice = 0;   // 0: the older logic below; 1 ring; 2 pipelined 256 x 128; 3 pipelined 256 x 256
     if constexpr (BL == B_K && (AL == A_K || AL == A_CONV)) {
-        if (ring && glds_ok && V.glds_pipe && !V.force_n128) {
+        // (grids beyond 16384 tiles of 128 x 128 -- the VAE's 512 x 512 convolutions at the training batch -- keep the older logic:
+        // the model's constants were measured on the UNet's shapes, profiles/r04_train_ring_selection_ab.log)
+        if (ring && glds_ok && V.glds_pipe && !V.force_n128 && cdiv64(P.M, 128) * cdiv64(P.N, 128) <= 16384) {
             const double kt = (double)(P.K / BK);
             const bool conv = AL == A_CONV;
             const double t_ring = (double)cdiv64(cdiv64(P.M, 128) * cdiv64(P.N, 128), 256) * (3.2 + kt * (conv ? 0.71 : 0.57));

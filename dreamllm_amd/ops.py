@@ -68,6 +68,9 @@ def _splitk_counters(device):
 # Kernel variant handed to every GEMM / conv launch (include/dreamllm_hip.h `variant`): 0 = automatic.  Python-side knob for
 # tests and microbenchmarks (`with ops.gemm_variant(259): ...`); the C library itself keeps no state.
 GEMM_VARIANT = 0
+# A/B knob (tools, bench): DREAMLLM_GEMM_NO_RING=1 sets bit 25 of `variant` on every automatic call: the library then never picks the
+# ring-buffered 128 x 128 kernel by itself (round 3's kernel selection), so one process can time both selections on one box.
+GEMM_NO_RING = (1 << 25) if os.environ.get("DREAMLLM_GEMM_NO_RING", "0") == "1" else 0
 
 
 # Attention kernel choice handed to dllm_attn_fwd / dllm_attn_bwd in bits 1-2 of `causal` (include/dreamllm_hip.h): 0 automatic,
@@ -292,6 +295,8 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
         if gm == 0 and GEMM_TUNE_GROUP_M and 2.0 * M * N * K >= _TUNE_MIN_FLOPS:   # opt-in tool, off in the product path
             gm = _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha)
         variant = (gm << 16) | persist
+    if (variant & 0xffff) == 0 and epi != "geglu":
+        variant |= GEMM_NO_RING
     with _GemmTimer((4.0 if epi == "geglu" else 2.0) * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
         check("dllm_gemm_bf16_splitk", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
               ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),
@@ -604,6 +609,37 @@ def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0
         g = g.to(p.dtype)
     check("dllm_adamw", _p(p), _p(g.contiguous()), _p(m), _p(v), p.numel(), _dt(p), _dt(m), float(lr), float(beta1),
           float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _p(grad_scale_dev), _stream())
+
+
+def _ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _multi_ok(t):
+    return t.dtype == torch.bfloat16 and t.is_contiguous() and t.numel() % 8 == 0 and t.data_ptr() % 16 == 0
+
+
+def adamw_multi_(ps, gs, ms, vs, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, grad_scale_dev=None):
+    """One fused AdamW update over a LIST of bf16 tensors (bf16 moments, shared hyper-parameters and step): the pointer table
+    travels as a kernel argument, 48 tensors per launch (include/dreamllm_hip.h: dllm_adamw_multi).  Every tensor must satisfy
+    `_multi_ok`; same update, element for element, as `adamw_`."""
+    if not ps:
+        return
+    _need_gpu(*ps)
+    n = (ctypes.c_int64 * len(ps))(*[t.numel() for t in ps])
+    check("dllm_adamw_multi", _ptr_array(ps), _ptr_array(gs), _ptr_array(ms), _ptr_array(vs), n, len(ps), float(lr), float(beta1),
+          float(beta2), float(eps), float(weight_decay), int(step), float(grad_scale), _p(grad_scale_dev), _stream())
+
+
+def sumsq_multi(xs):
+    """fp32 per-chunk partial sums of squares of a list of bf16 tensors (`_multi_ok`), in tensor-then-chunk order: a fixed layout, so
+    data-parallel replicas derive bit-identical norms.  ceil(len / 48) launches."""
+    _need_gpu(*xs)
+    n = (ctypes.c_int64 * len(xs))(*[t.numel() for t in xs])
+    parts = int(_lib.lib().dllm_sumsq_multi_parts(n, len(xs)))
+    out = torch.empty(parts, dtype=torch.float32, device=xs[0].device)
+    check("dllm_sumsq_multi", _ptr_array(xs), n, len(xs), _p(out), _stream())
+    return out
 
 
 SUMSQ_PARTS = 256
@@ -1094,7 +1130,8 @@ def conv2d_nhwc(x, w2d, CO, KH, KW, stride=1, pad=1, OH=None, OW=None, bias=None
         ws = _streamk_workspace(x.device)   # small grid, deep K: every tile's K loop is spread over the CUs (stream-K)
     with _GemmTimer(2.0 * N * OH * OW * CO * KH * KW * C, "conv"):
         check("dllm_conv2d_nhwc_bf16_splitk", _p(x), _p(w2d), _p(out), _p(bias), _p(residual), _p(image_bias), N, H, W, C, OH,
-              OW, CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), sk, _p(ws), _p(cnt), GEMM_VARIANT, _stream())
+              OW, CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), sk, _p(ws), _p(cnt),
+              GEMM_VARIANT | (GEMM_NO_RING if (GEMM_VARIANT & 0xffff) == 0 else 0), _stream())
     return out
 
 

@@ -100,7 +100,8 @@ int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int la
  * tiles, 257 plain LDS-DMA 256-tile kernel, 259 software-pipelined LDS-DMA kernel (the automatic choice for eligible shapes);
  * 264 the ring-buffered 128 x 128 kernel for small grids (forward linears / NHWC convs with K % 64 == 0; the automatic choice
  * wherever the register-staged 128-tile kernel used to run; ineligible calls fall back to the automatic choice);
- * bits 16-23 = GROUP_M of the grouped tile order (0 = per-layout default).  Tests pass 128 / 256 / 257 / 259 / 262 / 264 to cover
+ * bits 16-23 = GROUP_M of the grouped tile order (0 = per-layout default); bit 24 = XCD-synchronised persistent walk; bit 25 = never
+ * choose the ring-buffered kernel automatically (round 3's selection, an A/B knob).  Tests pass 128 / 256 / 257 / 259 / 262 / 264 to cover
  * every kernel family.  Anything else returns DLLM_ERR_SHAPE.  (A build with -DDLLM_BENCH_MODES additionally accepts the
  * wrong-result diagnostic modes 258 / 260 / 263 / 265 used by tools/; the shipped library does not contain them.) */
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
@@ -192,6 +193,15 @@ int dllm_adamw(void* p, const void* g, void* m, void* v, int64_t n, int param_dt
                float beta2, float eps, float weight_decay, int step, float grad_scale, const float* grad_scale_dev,
                void* stream);
 int dllm_sumsq(const void* x, int64_t n, int dtype, float* partials256, void* stream); /* 256 per-block partials, no atomics */
+/* Multi-tensor forms (round 4): p / g / m / v / x / n are HOST arrays of `count` entries (bf16 tensors, 16-byte aligned, n % 8 == 0,
+ * bf16 moments, shared hyper-parameters and step); the tables travel as kernel arguments, 48 tensors per launch: the 295 + 295
+ * per-tensor launches of the 7B step become 7 + 7.  dllm_sumsq_multi writes one fp32 partial per 32768-element chunk (fixed
+ * order; dllm_sumsq_multi_parts of them) for dllm_reduce_sum_f32. */
+int dllm_adamw_multi(void* const* p, const void* const* g, void* const* m, void* const* v, const int64_t* n, int count, float lr,
+                     float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                     const float* grad_scale_dev, void* stream);
+int64_t dllm_sumsq_multi_parts(const int64_t* n, int count);
+int dllm_sumsq_multi(const void* const* x, const int64_t* n, int count, float* partials, void* stream);
 int dllm_reduce_sum_f32(const float* in, int64_t n, float* out, void* stream);        /* fixed-order final reduction */
 
 /* ---------------------------------------------------------------------------------------------------- denoising loop

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import bound, check_scalar, check_tensor, rel_l2
+from conftest import AUTOCAST_YARDSTICK_SLACK, SLACK, bound, check_scalar, check_tensor, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -357,15 +357,17 @@ def test_sd_head_forward_vs_executed_reference(golden, xl, name):
             loss = head(inp["images"].to(DEV), enc, u, None)
     loss.backward()
     pre = f"{tag}.forward.{name}."
+    # SDXL: the fixture's bf16 yard-stick was taken under torch.autocast (norms / softmax in fp32): conftest.AUTOCAST_YARDSTICK_SLACK
+    sl = AUTOCAST_YARDSTICK_SLACK if xl else SLACK
     check_scalar(pre + "loss", loss, c["loss"], abs(float(c["loss_bf16"]) - float(c["loss"])))
-    check_tensor(pre + "grad_enc", enc.grad, c["grad_enc"].float(), rel_l2(c["grad_enc_bf16"].float(), c["grad_enc"].float()))
+    check_tensor(pre + "grad_enc", enc.grad, c["grad_enc"].float(), rel_l2(c["grad_enc_bf16"].float(), c["grad_enc"].float()), sl)
     check_tensor(pre + "grad_projector", head.projector.projector.weight.grad, c["grad_projector"].float(),
-                 rel_l2(c["grad_projector_bf16"].float(), c["grad_projector"].float()))
+                 rel_l2(c["grad_projector_bf16"].float(), c["grad_projector"].float()), sl)
     if "grad_u_enc" in c:
-        check_tensor(pre + "grad_u_enc", u.grad, c["grad_u_enc"].float(), rel_l2(c["grad_u_enc_bf16"].float(), c["grad_u_enc"].float()))
+        check_tensor(pre + "grad_u_enc", u.grad, c["grad_u_enc"].float(), rel_l2(c["grad_u_enc_bf16"].float(), c["grad_u_enc"].float()), sl)
     if xl:
         check_tensor(pre + "grad_global_projector", head.global_projector.projector.weight.grad, c["grad_global_projector"].float(),
-                     rel_l2(c["grad_global_projector_bf16"].float(), c["grad_global_projector"].float()))
+                     rel_l2(c["grad_global_projector_bf16"].float(), c["grad_global_projector"].float()), sl)
 
 
 @pytest.mark.parametrize("use_graph", [True, False])

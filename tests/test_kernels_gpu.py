@@ -139,7 +139,7 @@ def test_layernorm_fwd_bwd(rows, D):
 
 
 # ----------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[128, 256, 257, 259, 262, 264])
+@pytest.fixture(params=[128, 256, 257, 259, 262, 264, 266])
 def gemm_tile(request):
     """run the GEMM tests once per block-tile variant (128x128 / 4 waves and 256x256 / 8 waves)"""
     from dreamllm_amd import ops
@@ -563,6 +563,50 @@ def test_adamw_matches_torch():
         pt.grad = ga[8:8 + n8].float().cpu() * 0.37
         opt.step()
     assert rel_l2(bufs["vec"][0], pt) < 6e-3          # bf16 parameters and moments: three roundings per step
+
+
+def test_adamw_and_grad_norm_multi_tensor_match_per_tensor_launches():
+    """Multi-tensor AdamW / sum of squares (48 tensors per launch, tables as kernel arguments) against the per-tensor launches on
+    130 tensors of assorted sizes (empty-ish, one chunk, chunk boundary + 8, several chunks; > 2 launches' worth): parameters and
+    both moments over three steps with a device-side clip factor, and the clipped-norm optimizer end to end (HipAdamW with and
+    without `multi_tensor`), including tensors the multi path must leave to the scalar kernel (odd size, fp32)."""
+    ops = _ops()
+    from dreamllm_amd.optim import HipAdamW
+    torch.manual_seed(21)
+    sizes = [8, 4096, 32768, 32776, 3 * 32768 + 64, 100000 - 100000 % 8, 1 << 20] * 18 + [24, 262144, 8, 65536]
+    assert len(sizes) == 130
+    mk = lambda scale: [(torch.randn(n) * scale).to(BF).to(DEV) for n in sizes]
+    p1, g = mk(1.0), mk(0.1)
+    p2 = [t.clone() for t in p1]
+    m1, v1 = [torch.zeros_like(t) for t in p1], [torch.zeros_like(t) for t in p1]
+    m2, v2 = [torch.zeros_like(t) for t in p1], [torch.zeros_like(t) for t in p1]
+    coef = torch.tensor([0.61], device=DEV)
+    for step in range(1, 4):
+        ops.adamw_multi_(p1, g, m1, v1, 1e-2, 0.9, 0.98, 1e-8, 0.1, step, 1.0, coef)
+        for a, b, c, d in zip(p2, g, m2, v2):
+            ops.adamw_(a, b, c, d, 1e-2, 0.9, 0.98, 1e-8, 0.1, step, 1.0, coef)
+    for a, b in zip(p1 + m1 + v1, p2 + m2 + v2):     # same formula; two kernels, -ffast-math may contract them differently
+        assert rel_l2(a, b.float()) < 2e-3 and float((a != b).float().mean()) < 0.05
+    parts = ops.sumsq_multi(g)
+    ref = sum(float((t.double() ** 2).sum()) for t in g)
+    assert abs(float(ops.reduce_sum_f32(parts)) - ref) < 1e-4 * ref
+    assert torch.equal(ops.sumsq_multi(g), parts)                                     # deterministic
+    # optimizer end to end, mixed bag of tensors
+    def run(multi):
+        torch.manual_seed(5)
+        ps = [torch.nn.Parameter((torch.randn(n) * 0.5).to(BF).to(DEV)) for n in (4096, 1001, 65536, 8, 32768 * 2 + 8)]
+        ps.append(torch.nn.Parameter(torch.randn(777, device=DEV)))                    # fp32, odd size: per-tensor kernel
+        opt = HipAdamW(ps, lr=1e-2, betas=(0.9, 0.98), weight_decay=0.05, max_grad_norm=1.0, multi_tensor=multi)
+        for it in range(3):
+            for i, q in enumerate(ps):
+                q.grad = (torch.randn(q.shape, generator=torch.Generator().manual_seed(100 * it + i)) * 0.3).to(q.dtype).to(DEV)
+            opt.step()
+        return [q.detach().clone() for q in ps], float(opt.last_grad_norm)
+    a, na = run(True)
+    b, nb = run(False)
+    assert abs(na - nb) < 1e-4 * nb
+    for x, y in zip(a, b):
+        assert rel_l2(x, y.float()) < 2e-3
 
 
 # ----------------------------------------------------------------------------- autograd wrappers
