@@ -187,7 +187,7 @@ class Attention(nn.Module):
         return self.to_out[0](o.reshape(N, S, C), residual=residual)
 
 
-GEGLU_FUSED_MAX_ROWS = 8192
+GEGLU_FUSED_MAX_ROWS = 1 << 30
 
 
 class GEGLU(nn.Module):
@@ -196,9 +196,9 @@ class GEGLU(nn.Module):
         self.proj = _Lin(dim, inner * 2)
 
     def forward(self, x):
-        # inference / denoising loop at small batch (M <= 8192 rows: UNet batch 2): projection + GEGLU in one launch.  At larger M the
-        # fused form's 128 x 64 output tiles re-read the activations twice as often and it only ties the two-launch path
-        # (profiles/r04_unet_gemm_b16.log: 286 vs 243 + 45 us at M = 65536).
+        # inference / denoising loop: projection + GEGLU in one launch.  In the loop's graph the fused form wins at every level but
+        # one, where it ties (UNet batch 16: 64 x 64 level 286 us against 243 + ~120 us for GEMM + element-wise pass; 32 x 32 level
+        # 213 against 172 + ~40 us; profiles/r04_unet_gemm_b16.log, r04_denoise_b8_launch_table.txt).
         if not (torch.is_grad_enabled() and x.requires_grad) and x.numel() // x.shape[-1] <= GEGLU_FUSED_MAX_ROWS:
             y = ops.linear_geglu(x, self.proj.weight, self.proj.bias)
             if y is not None:

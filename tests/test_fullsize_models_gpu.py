@@ -84,7 +84,7 @@ def test_sd21_unet_full_size_forward_and_context_gradient():
         y_ng = m(x.to(BF), t, ctx.to(BF)).sample
         assert torch.equal(m(x.to(BF), t, ctx.to(BF), context_cache=m.prepare_context(ctx.to(BF))).sample, y_ng)
     check_tensor("fullsize.sd21_unet.forward(no_grad, fused GEGLU)", y_ng, yr, rel_l2(yb, yr))
-    assert rel_l2(y_ng, y.float()) < 1e-2
+    assert rel_l2(y_ng, y.float()) < 2.5e-2   # two bf16 programs, each ~1e-2 from the fp32 oracle
 
 
 def test_sdxl_unet_full_size_forward():
