@@ -229,11 +229,7 @@ __global__ __launch_bounds__(1024) void gn_small_kernel(const bf16* __restrict__
 // totals are then summed in slot order by every block: deterministic, identical in all S blocks.  All NB * G * S blocks are
 // co-resident by construction (host: at most 512 blocks of 1024 threads); should they not be (a GPU shared between processes), a
 // block that waited ~2 ms computes the whole slice's statistics itself: the wait cannot deadlock and cannot produce a wrong result.
-// NP > 0 (round 4): the block's slice lives in REGISTERS between the two passes -- every thread requests its (at most NP) 4-byte
-// pixel pairs in ONE batch, sums them, and after the meeting point normalises and stores from the same registers: one memory round
-// trip instead of ceil(NP / 4) dependent ones per pass and no second read (the 960- / 1920-channel GroupNorms of the up blocks were
-// four round trips per pass).  NP = 0 keeps the looping form for slices that do not fit.
-template <int S, int NP = 0>
+template <int S>
 __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __restrict__ x, const bf16* __restrict__ gamma,
                                                               const bf16* __restrict__ beta, bf16* __restrict__ y,
                                                               float* __restrict__ mean_o, float* __restrict__ rstd_o,
@@ -257,25 +253,7 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the epoch is read BEFORE this block arrives
     }
     float s1 = 0.f, s2 = 0.f;
-    constexpr int NPR = NP > 0 ? NP : 1;
-    bf16x2 keep[NPR];
-    if constexpr (NP > 0) {
-        const bf16* px = x + base + (int64_t)(p0 + r) * C;
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const bool ok = live && p0 + r + i * R < p1;
-            bf16x2 z;
-            z[0] = (bf16)0.f;
-            z[1] = (bf16)0.f;
-            keep[i] = ok ? *reinterpret_cast<const bf16x2*>(px + (int64_t)i * stride) : z;
-        }
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const float a = (float)keep[i][0], b = (float)keep[i][1];
-            s1 += a + b;
-            s2 += a * a + b * b;
-        }
-    } else if (live) {
+    if (live) {
         const bf16* px = x + base + (int64_t)(p0 + r) * C;
         int p = p0 + r;
         for (; p + 3 * R < p1; p += 4 * R, px += 4 * stride) {
@@ -361,34 +339,18 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
         const float b0 = (float)beta[c] - mean * a0, b1 = (float)beta[c + 1] - mean * a1;
         const bf16* px = x + base + (int64_t)(p0 + r) * C;
         bf16* py = y + base + (int64_t)(p0 + r) * C;
-        if constexpr (NP > 0) {
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                if (p0 + r + i * R >= p1) break;
-                float z0 = (float)keep[i][0] * a0 + b0, z1 = (float)keep[i][1] * a1 + b1;
-                if (act) {
-                    z0 = silu_f(z0);
-                    z1 = silu_f(z1);
-                }
-                bf16x2 o;
-                o[0] = (bf16)z0;
-                o[1] = (bf16)z1;
-                *reinterpret_cast<bf16x2*>(py + (int64_t)i * stride) = o;
-            }
-        } else {
 #pragma unroll 4
-            for (int p = p0 + r; p < p1; p += R, px += stride, py += stride) {
-                const bf16x2 v = *reinterpret_cast<const bf16x2*>(px);
-                float z0 = (float)v[0] * a0 + b0, z1 = (float)v[1] * a1 + b1;
-                if (act) {
-                    z0 = silu_f(z0);
-                    z1 = silu_f(z1);
-                }
-                bf16x2 o;
-                o[0] = (bf16)z0;
-                o[1] = (bf16)z1;
-                *reinterpret_cast<bf16x2*>(py) = o;
+        for (int p = p0 + r; p < p1; p += R, px += stride, py += stride) {
+            const bf16x2 v = *reinterpret_cast<const bf16x2*>(px);
+            float z0 = (float)v[0] * a0 + b0, z1 = (float)v[1] * a1 + b1;
+            if (act) {
+                z0 = silu_f(z0);
+                z1 = silu_f(z1);
             }
+            bf16x2 o;
+            o[0] = (bf16)z0;
+            o[1] = (bf16)z1;
+            *reinterpret_cast<bf16x2*>(py) = o;
         }
     }
 }
@@ -515,26 +477,9 @@ int dllm_groupnorm_fwd_split(const void* x, const void* gamma, const void* beta,
     constexpr int S = 4;
     if ((int64_t)NB * HW * C > ((int64_t)1 << 23) || (cpg & 1) || cpg > 512 || HW < 1024 || (HW % S) != 0 || NB * G * S > 512)
         return DLLM_ERR_SHAPE;
-    // pixel pairs per thread of a block's slice: R = 1024 / (cpg / 2) pixel rows per pass over HW / S pixels
-    const int R = 1024 / (cpg >> 1);
-    const int np = (HW / S + R - 1) / R;
-#define DLLM_GN_SPLIT(NPV)                                                                                                          \
-    hipLaunchKernelGGL((gn_small_split_kernel<S, NPV>), dim3(NB * G * S), dim3(1024), 0, (hipStream_t)stream, (const bf16*)x,        \
-                       (const bf16*)gamma, (const bf16*)beta, (bf16*)y, mean, rstd, reinterpret_cast<unsigned*>(sync), HW, C, G, eps, \
-                       act)
-    // the register-resident forms need up to 104 registers per lane: one 1024-thread block per CU.  All blocks of the launch must be
-    // co-resident (they meet inside the kernel), so larger launches keep the 38-register looping form (two blocks per CU).
-    if (NB * G * S > dllm_num_cus())
-        DLLM_GN_SPLIT(0);
-    else if (np <= 8)
-        DLLM_GN_SPLIT(8);
-    else if (np <= 16)
-        DLLM_GN_SPLIT(16);
-    else if (np <= 32)
-        DLLM_GN_SPLIT(32);
-    else
-        DLLM_GN_SPLIT(0);
-#undef DLLM_GN_SPLIT
+    hipLaunchKernelGGL(gn_small_split_kernel<S>, dim3(NB * G * S), dim3(1024), 0, (hipStream_t)stream, (const bf16*)x,
+                       (const bf16*)gamma, (const bf16*)beta, (bf16*)y, mean, rstd, reinterpret_cast<unsigned*>(sync), HW, C, G, eps,
+                       act);
     return dllm_check_launch();
 }
 
