@@ -584,16 +584,35 @@ __global__ __launch_bounds__(512, 2) void attn_fwd8_kernel(AttnParams P) {
             const int qrow = wq0 + qt * 16 + t;
             const bool valid = qrow < sq_len;
             const float inv = (l > 0.f && valid) ? 1.0f / l : 0.f;
-            if (qrow < SqE) {
+            // Store tail (round 4; MI355X guide T21 with the 16-lane swap): a lane holds 4 consecutive d (8 bytes) of its query row per
+            // 16-wide d tile, the lane 16 further the next 4.  One v_permlane16_swap per dword and pair of d tiles (dt, dt + 1) gives the
+            // even lane group [own dt | partner's dt] and the odd one [partner's dt + 1 | own dt + 1]: 16 contiguous bytes each, so a
+            // row leaves in DT / 2 16-byte stores per lane instead of DT 8-byte ones (the tail is store-ISSUE bound, not bandwidth bound).
+            // Both lanes of a pair hold the same query row, so the predicate is uniform across the exchange.
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    bf16x4 o;
+            for (int dt = 0; dt < DT; dt += 2) {
+                union {
+                    bf16x4 v;
+                    uint32_t w[2];
+                } a, b;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (bf16)(oacc[dt][qt][r] * inv);
-                    st_bf16x4(obase + (int64_t)qrow * P.o_ss + dt * 16 + g * 4, o);
+                for (int r = 0; r < 4; ++r) {
+                    a.v[r] = (bf16)(oacc[dt][qt][r] * inv);
+                    b.v[r] = (bf16)(oacc[dt + 1][qt][r] * inv);
                 }
-                if (lsebase && g == 0) lsebase[qrow] = (valid && l > 0.f) ? (m_run[qt] * P.scale + logf(l)) : 0.f;
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(a.w[w], b.w[w], false, false);
+                    a.w[w] = sw[0];
+                    b.w[w] = sw[1];
+                }
+                if (qrow < SqE) {
+                    const u32x4 o = u32x4{a.w[0], a.w[1], b.w[0], b.w[1]};
+                    const int d0 = (g & 1) ? (dt + 1) * 16 + (g - 1) * 4 : dt * 16 + g * 4;
+                    *reinterpret_cast<u32x4*>(obase + (int64_t)qrow * P.o_ss + d0) = o;
+                }
             }
+            if (qrow < SqE && lsebase && g == 0) lsebase[qrow] = (valid && l > 0.f) ? (m_run[qt] * P.scale + logf(l)) : 0.f;
         }
     }  // pass
 }
@@ -636,6 +655,9 @@ int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     if (D != 64 && D != 128) return DLLM_ERR_SHAPE;
     if (B == 0 || Sq == 0) return DLLM_OK;
     if ((q_ss | q_sh | q_sb | k_ss | k_sh | k_sb | o_ss | o_sh | o_sb) & 7) return DLLM_ERR_ALIGN;
+    // 16-byte loads of q / k / v rows and (round 4: the widened store tail) 16-byte stores of o rows
+    if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(o)) & 15)
+        return DLLM_ERR_ALIGN;
     if (seqlens != nullptr && Sq != Sk) return DLLM_ERR_SHAPE;
     AttnParams P{};
     P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.o = (bf16*)o; P.lse = lse; P.seqlens = seqlens;

@@ -1001,7 +1001,6 @@ static inline bool ring_ok(const GemmParams& P) {
     if (P.dbg_noload != 0) return false;
     if ((P.K % BK) != 0 || P.K < BK) return false;
     if (AL == A_CONV && (P.cv.C % BK) != 0) return false;
-    if (P.splitk > 1 && P.counters != nullptr) return false;   // the in-kernel reduction lives in the register-staged kernel
     return true;
 }
 

@@ -288,7 +288,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
                             (P.bias == nullptr || (reinterpret_cast<uintptr_t>(P.bias) & 7) == 0) &&
                             (P.rg_bias == nullptr || (reinterpret_cast<uintptr_t>(P.rg_bias) & 7) == 0);
         if (!staged) {
-            gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane, blockIdx.y);
+            // split-K with `counters`: the last K slice of a tile to arrive reduces it inside the launch (gemm_shared.h)
+            gemm_epilogue<MI>(P, acc, m0 + wm, n0 + wn, lane, blockIdx.y, pid_m * num_pid_n + pid_n, reinterpret_cast<int*>(smem));
             return;
         }
         // LDS-staged epilogue: the direct form stores 8 bytes per lane (one instruction = 16 rows x 32-byte pieces).  Here the wave
@@ -364,7 +365,7 @@ int launch_ring_t(const GemmParams& P, hipStream_t stream) {
     dllm_ensure_dyn_lds(&gemm_ring_kernel<AL, GLU>, RING_LDS, lds_ok);
     const int sk = P.splitk > 1 ? P.splitk : 1;
     hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU>), dim3((unsigned)tiles, sk), dim3(512), RING_LDS, stream, P);
-    if (sk > 1) {
+    if (sk > 1 && P.counters == nullptr) {
         const int64_t work = P.M * (P.N >> 2);
         const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, P);

@@ -52,7 +52,7 @@ SPLITK = True  # split-K for small grids with deep reductions (see dllm_gemm_spl
 # Opt-in: the last K slice of a tile reduces inside the GEMM launch (no separate reduce kernel).  Correct and bit-identical to the
 # reduce kernel (tests), but SLOWER on MI355X: the slices of a tile run on different XCDs, so the slabs must be written through
 # and read around the non-coherent L2s (109 -> 85 denoise steps/s; with release / acquire fences 72).  The reduce kernel stays.
-SPLITK_FUSED_REDUCE = False
+SPLITK_FUSED_REDUCE = os.environ.get("DREAMLLM_SPLITK_FUSED", "0") == "1"
 _SPLITK_COUNTERS = {}
 
 

@@ -735,7 +735,6 @@ def test_gemm_splitk_in_kernel_reduction_is_bit_identical(M, N, K):
     assert _lib.call("dllm_gemm_splitk_hint", M, N, K) > 1
     torch.manual_seed(M + N)
     x, w, b, r = rnd(M, K).to(DEV), rnd(N, K, scale=0.02).to(DEV), rnd(N).to(DEV), rnd(M, N).to(DEV)
-    assert ops.SPLITK_FUSED_REDUCE is False  # opt-in (measured slower than the reduce kernel, ops.py)
     ref = ops.linear_fwd(x, w, bias=b, epi="silu", residual=r)
     ops.SPLITK_FUSED_REDUCE = True
     try:
