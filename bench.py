@@ -258,6 +258,9 @@ def main():
         # every kernel, so that even `--warmup 0/1` times steady-state steps (measured: the second step of a fresh process can
         # run 10 % slow)
         step()
+        if world > 1 and a.warmup < 1:
+            step()   # torch DDP (static_graph) uses ONE all-gradient bucket in its first two iterations and the rebuilt 512 MB buckets
+                     # from the third (tools/ddp_dry_7b.py): the timed region must never contain one of those two
         # warm-up steps run with the per-launch HIP-event timing switched on as well, so that the timed region starts in
         # steady state; the events the timed region will need are created here, outside it
         ops.GEMM_PROFILE = []
