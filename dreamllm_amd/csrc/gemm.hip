@@ -36,6 +36,8 @@ struct Variant {
     int force_n128 = 0;  // tile code 262: the 256 x 128 pipelined kernel wherever it is eligible (tests)
     int persist = 0;     // bit 24: XCD-synchronised persistent walk of the pipelined 256-tile kernel (needs the workspace)
     int force_ring = 0;  // tile code 264: the 128 x 128 ring-buffered kernel (gemm_ring.hip) wherever it is eligible (tests, tools)
+    int streamk_ws = 0;  // bit 26: with splitk <= 1 the caller's workspace is a stream-K workspace of dllm_gemm_streamk_ws_bytes() bytes (ADVICE r03:
+                         // without the bit a workspace passed with splitk <= 1 is ignored, as before round 3 -- no unchecked 128 MiB writes)
     int no_ring = 0;     // bit 25: never pick the ring-buffered kernel by itself (the round-3 selection: A/B knob of tools / bench)
     int force_mfma32 = 0;  // tile code 266: the MFMA 32x32x16 experiment (gemm_mfma32.hip) wherever it is eligible (tools)
 };
@@ -47,8 +49,9 @@ static inline int parse_variant(int variant, Variant& v) {
     ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265;
     v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
 #endif
-    if (!ok || (variant >> 26) != 0) return DLLM_ERR_SHAPE;
+    if (!ok || (variant >> 27) != 0) return DLLM_ERR_SHAPE;
     v.no_ring = (variant >> 25) & 1;
+    v.streamk_ws = (variant >> 26) & 1;
     v.persist = (variant >> 24) & 1;
     v.use_glds = (tile == 0 || tile >= 257);
     v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 262 || tile == 263 || tile == 265);
@@ -1047,7 +1050,7 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     }
     if constexpr (!(AL == A_M && BL == B_K)) {
         int tail = 0, w = 0, blocks = 0;
-        if (P.ws != nullptr && glds_ok && V.glds_pipe && V.force_tile == 0 && !V.force_n128 && P.dbg_noload == 0 &&
+        if (P.ws != nullptr && V.streamk_ws && glds_ok && V.glds_pipe && V.force_tile == 0 && !V.force_n128 && P.dbg_noload == 0 &&
             streamk_plan_small(P.M, P.N, P.K, tail, w, blocks)) {
             constexpr int LDS = 2 * 2 * 256 * BK * 2;
             GemmParams Q = P;
@@ -1124,7 +1127,7 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
                     int full = 0, tail = 0, w = 0, blocks = 0;
                     // XCD-synchronised persistent walk (opt-in, variant bit 24): grids of at least 4 rounds, workspace present
                     static std::atomic<uint64_t> lds4_ok{0};
-                    const bool persist = V.persist && P.ws != nullptr && P.splitk <= 1 && P.dbg_noload == 0 && tiles256 >= 1024;
+                    const bool persist = V.persist && V.streamk_ws && P.ws != nullptr && P.splitk <= 1 && P.dbg_noload == 0 && tiles256 >= 1024;
                     auto launch_main = [&](const GemmParams& Q, int64_t ntiles) {
                         if (persist) {
                             dllm_ensure_dyn_lds(&gemm_pipe_persist_kernel<AL, BL>, LDS, lds4_ok);
@@ -1133,7 +1136,7 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
                             hipLaunchKernelGGL((gemm_pipe_kernel<AL, BL>), dim3((unsigned)ntiles), dim3(512), LDS, stream, Q);
                         }
                     };
-                    if (P.ws != nullptr && P.splitk <= 1 && P.dbg_noload == 0 && streamk_plan(P.M, P.N, P.K, full, tail, w, blocks)) {
+                    if (P.ws != nullptr && V.streamk_ws && P.splitk <= 1 && P.dbg_noload == 0 && streamk_plan(P.M, P.N, P.K, full, tail, w, blocks)) {
                         // whole rounds, then the last partial round's K loops spread evenly over the CUs, then the fix-up
                         static std::atomic<uint64_t> lds3_ok{0};
                         dllm_ensure_dyn_lds(&gemm_pipe_tail_kernel<AL, BL>, LDS, lds3_ok);

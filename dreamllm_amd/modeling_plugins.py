@@ -508,10 +508,13 @@ class StableDiffusionHead(MultimodalHead):
                     self.unet(x_in, None, emb_static, context_cache=ctx_static, nhwc_io=True, return_dict=False, time_bias=tb_static)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # capture ON the warm-up stream: the per-(device, stream) buffers of the operators (GroupNorm meeting slots, stream-K
+            # workspace, split-K counters) were allocated by the warm-up calls above, outside the capture -- a different capture
+            # stream would allocate new ones from the graph's private pool
+            with torch.cuda.graph(graph, stream=side):
                 pred = self.unet(x_in, None, emb_static, context_cache=ctx_static, nhwc_io=True, return_dict=False,
                                  time_bias=tb_static)[0]
-            ent = cache[key] = dict(graph=graph, x_in=x_in, tb=tb_static, ctx=ctx_static, pred=pred)
+            ent = cache[key] = dict(graph=graph, x_in=x_in, tb=tb_static, ctx=ctx_static, pred=pred, stream=side)  # (keeps the stream's handle alive)
         for k, v in ctx_now.items():
             for dst, src in zip(ent["ctx"][k], v):
                 dst.copy_(src)

@@ -217,6 +217,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, need_dw=True):
 # Stream-K tail (include/dreamllm_hip.h): one 128 MiB fp32 workspace per device, handed to the GEMM when the library says the
 # problem's last round of tiles would otherwise leave most of the chip idle.  DREAMLLM_STREAMK=0 switches it off (A/B knob).
 STREAMK = os.environ.get("DREAMLLM_STREAMK", "1") != "0"
+STREAMK_WS_BIT = 1 << 26   # `variant` bit: the workspace handed over with splitk <= 1 is a stream-K workspace (include/dreamllm_hip.h)
 _STREAMK_WS, _STREAMK_HINT = {}, {}
 
 
@@ -285,12 +286,13 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     if sk == 1 and (GEMM_VARIANT & 0xffff) in (0, 259):
         if STREAMK and _streamk_hint(M, N, K, layout_a, layout_b):
             ws = _streamk_workspace(a.device)   # the library spreads the last partial round of 256-tiles over the CUs (stream-K tail)
+            persist = STREAMK_WS_BIT            # bit 26: "this workspace holds dllm_gemm_streamk_ws_bytes() bytes"
         if GEMM_PERSIST and -(-M // 256) * -(-N // 256) >= 1024 and K % 64 == 0 and not torch.cuda.is_current_stream_capturing():
             ws = _streamk_workspace(a.device)
-            persist = 1 << 24
+            persist = (1 << 24) | STREAMK_WS_BIT
     cnt = _splitk_counters(a.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-M // 128) * -(-N // 128) <= 16384) else None
-    variant = GEMM_VARIANT
-    if variant == 0 and sk == 1:
+    variant = GEMM_VARIANT | (persist & STREAMK_WS_BIT)
+    if (variant & 0xffff) == 0 and sk == 1 and (variant >> 16) & 0xff == 0:
         gm = _GROUP_M_TABLE.get((layout_a, layout_b, M, N, K), 0)
         if gm == 0 and GEMM_TUNE_GROUP_M and 2.0 * M * N * K >= _TUNE_MIN_FLOPS:   # opt-in tool, off in the product path
             gm = _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha)
@@ -1126,12 +1128,14 @@ def conv2d_nhwc(x, w2d, CO, KH, KW, stride=1, pad=1, OH=None, OW=None, bias=None
     sk = _splitk_hint(Mg, CO, KH * KW * C)
     ws = torch.empty(sk * Mg * CO, dtype=torch.float32, device=x.device) if sk > 1 else None
     cnt = _splitk_counters(x.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-Mg // 128) * -(-CO // 128) <= 16384) else None
+    skbit = 0
     if sk == 1 and STREAMK and GEMM_VARIANT == 0 and C % 64 == 0 and _streamk_hint(Mg, CO, KH * KW * C, 2, 0):
         ws = _streamk_workspace(x.device)   # small grid, deep K: every tile's K loop is spread over the CUs (stream-K)
+        skbit = STREAMK_WS_BIT
     with _GemmTimer(2.0 * N * OH * OW * CO * KH * KW * C, "conv"):
         check("dllm_conv2d_nhwc_bf16_splitk", _p(x), _p(w2d), _p(out), _p(bias), _p(residual), _p(image_bias), N, H, W, C, OH,
               OW, CO, KH, KW, stride, pad, int(up2), int(even_only), EPI[epi], _dt(out), sk, _p(ws), _p(cnt),
-              GEMM_VARIANT | (GEMM_NO_RING if (GEMM_VARIANT & 0xffff) == 0 else 0), _stream())
+              GEMM_VARIANT | skbit | (GEMM_NO_RING if (GEMM_VARIANT & 0xffff) == 0 else 0), _stream())
     return out
 
 

@@ -101,7 +101,10 @@ int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int la
  * 264 the ring-buffered 128 x 128 kernel for small grids (forward linears / NHWC convs with K % 64 == 0; the automatic choice
  * wherever the register-staged 128-tile kernel used to run; ineligible calls fall back to the automatic choice);
  * bits 16-23 = GROUP_M of the grouped tile order (0 = per-layout default); bit 24 = XCD-synchronised persistent walk; bit 25 = never
- * choose the ring-buffered kernel automatically (round 3's selection, an A/B knob).  Tests pass 128 / 256 / 257 / 259 / 262 / 264 to cover
+ * choose the ring-buffered kernel automatically (round 3's selection, an A/B knob); bit 26 = "with splitk <= 1 my workspace is a
+ * stream-K workspace of dllm_gemm_streamk_ws_bytes() bytes" -- without it a workspace passed with splitk <= 1 is IGNORED (round 4,
+ * round 3 treated any non-NULL workspace as 128 MiB of slab space; a caller re-using its smaller split-K buffer with
+ * splitk = 1 would have been written out of bounds).  Tests pass 128 / 256 / 257 / 259 / 262 / 264 to cover
  * every kernel family.  Anything else returns DLLM_ERR_SHAPE.  (A build with -DDLLM_BENCH_MODES additionally accepts the
  * wrong-result diagnostic modes 258 / 260 / 263 / 265 used by tools/; the shipped library does not contain them.) */
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
