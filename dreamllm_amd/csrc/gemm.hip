@@ -38,18 +38,20 @@ struct Variant {
     int force_ring = 0;  // tile code 264: the 128 x 128 ring-buffered kernel (gemm_ring.hip) wherever it is eligible (tests, tools)
     int streamk_ws = 0;  // bit 26: with splitk <= 1 the caller's workspace is a stream-K workspace of dllm_gemm_streamk_ws_bytes() bytes (ADVICE r03:
                          // without the bit a workspace passed with splitk <= 1 is ignored, as before round 3 -- no unchecked 128 MiB writes)
+    int ring_stages = 0;  // tile codes 267 / 268: force the four- / two-stage ring (0: the launcher decides)
     int no_ring = 0;     // bit 25: never pick the ring-buffered kernel by itself (the round-3 selection: A/B knob of tools / bench)
     int force_mfma32 = 0;  // tile code 266: the MFMA 32x32x16 experiment (gemm_mfma32.hip) wherever it is eligible (tools)
 };
 static inline int parse_variant(int variant, Variant& v) {
     const int tile = variant & 0xffff;
     v.group_m = (variant >> 16) & 0xff;
-    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262 || tile == 264 || tile == 266;
+    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262 || tile == 264 || tile == 266 || tile == 267 || tile == 268;
 #ifdef DLLM_BENCH_MODES
     ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265;
     v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
 #endif
-    if (!ok || (variant >> 27) != 0) return DLLM_ERR_SHAPE;
+    if (!ok || (variant >> 28) != 0) return DLLM_ERR_SHAPE;
+    if ((variant >> 27) & 1) v.ring_stages = -1;   // bit 27: the ring kernel always with four stages (round-4 A/B knob)
     v.no_ring = (variant >> 25) & 1;
     v.streamk_ws = (variant >> 26) & 1;
     v.persist = (variant >> 24) & 1;
@@ -57,7 +59,8 @@ static inline int parse_variant(int variant, Variant& v) {
     v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 262 || tile == 263 || tile == 265);
     v.force_tile = tile >= 257 ? 256 : tile;
     v.force_n128 = tile == 262;
-    v.force_ring = tile == 264;
+    v.force_ring = tile == 264 || tile == 267 || tile == 268;   // 267: four-stage ring forced, 268: two-stage ring forced (tools)
+    if (tile == 267 || tile == 268) v.ring_stages = tile == 267 ? -1 : 1;
     v.force_mfma32 = tile == 266;
     if (v.force_ring) v.force_tile = 0;
     return DLLM_OK;
@@ -1011,8 +1014,8 @@ template <int AL, int BL>
 int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     if (P.M <= 0 || P.N <= 0) return DLLM_OK;
     bool ring = ring_ok<AL, BL>(P);
-    if (P.epi == EPI_GEGLU) return ring ? dllm_launch_gemm_ring(P, AL, stream) : DLLM_ERR_SHAPE;   // only the ring kernel pairs the columns
-    if (V.force_ring && ring) return dllm_launch_gemm_ring(P, AL, stream);
+    if (P.epi == EPI_GEGLU) return ring ? dllm_launch_gemm_ring(P, AL, stream, V.ring_stages) : DLLM_ERR_SHAPE;   // only the ring kernel pairs the columns
+    if (V.force_ring && ring) return dllm_launch_gemm_ring(P, AL, stream, V.ring_stages);
     if constexpr (AL == A_K && BL == B_K) {
         if (V.force_mfma32 && (P.M % 256) == 0 && (P.N % 256) == 0 && (P.K % BK) == 0 && P.K >= BK && !P.out_f32 && P.bias == nullptr &&
             P.residual == nullptr && P.rg_bias == nullptr && P.epi == 0 && !P.accumulate && P.splitk <= 1 && (P.ldc & 7) == 0 &&
@@ -1029,7 +1032,7 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     const double e256 = tile_eff(P.M, P.N, 256, glds_ok ? 1.15 : 1.0);
     const double e128 = ring ? tile_eff(P.M, P.N, 128, 1.0, 1) : tile_eff(P.M, P.N, 128, 0.85);
     bool pick256 = e256 >= e128;
-    if (P.splitk > 1) return ring ? dllm_launch_gemm_ring(P, AL, stream) : launch_gemm_t<AL, BL, 128>(P, stream);
+    if (P.splitk > 1) return ring ? dllm_launch_gemm_ring(P, AL, stream, V.ring_stages) : launch_gemm_t<AL, BL, 128>(P, stream);
     // Ring-eligible problems (forward linears, plain-geometry convs): three-way choice by estimated time = rounds of 256 blocks x
     // (fixed + K tiles x per-K-tile cost), the per-round figures measured on the UNet's shapes at batch 2 and 16 with weights
     // streamed from HBM (tools/unet_gemm_bench.py, profiles/r04_unet_gemm_b{2,16}.log; microseconds): ring 128 x 128: 3.2 + 0.57 k
@@ -1042,7 +1045,10 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
         if (ring && glds_ok && V.glds_pipe && !V.force_n128 && cdiv64(P.M, 128) * cdiv64(P.N, 128) <= 16384) {
             const double kt = (double)(P.K / BK);
             const bool conv = AL == A_CONV;
-            const double t_ring = (double)cdiv64(cdiv64(P.M, 128) * cdiv64(P.N, 128), 256) * (3.2 + kt * (conv ? 0.71 : 0.57));
+            const int64_t tiles128 = cdiv64(P.M, 128) * cdiv64(P.N, 128);
+            // (grids of more than one block per CU with K <= 2048 run the two-stage ring, two blocks per CU: 2.3 + 0.48 k per round)
+            const bool two_stage = V.ring_stages >= 0 && tiles128 > 256 && P.K <= 32 * BK;
+            const double t_ring = (double)cdiv64(tiles128, 256) * (two_stage ? 2.3 + kt * (conv ? 0.6 : 0.48) : 3.2 + kt * (conv ? 0.71 : 0.57));
             const double t_n128 = (double)cdiv64(cdiv64(P.M, 256) * cdiv64(P.N, 128), 256) * (14.0 + kt * 1.13);
             const double t_256 = (double)cdiv64(tiles256, 256) * (27.0 + kt * 1.5);
             choice = (t_ring <= t_n128 && t_ring <= t_256) ? 1 : (t_n128 < t_256 ? 2 : 3);
@@ -1074,7 +1080,7 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     }
     if constexpr (BL == B_K && (AL == A_K || AL == A_CONV)) {
         // narrow outputs (N = 320: 62 % of two 256-wide tiles, 83 % of three 128-wide ones): the pipelined kernel on 256 x 128 tiles
-        if (choice == 1) return dllm_launch_gemm_ring(P, AL, stream);
+        if (choice == 1) return dllm_launch_gemm_ring(P, AL, stream, V.ring_stages);
         if (choice == 3) pick256 = true;
         bool n128 = V.force_n128 != 0 || choice == 2;
         if (choice == 0 && !n128 && V.force_tile == 0 && glds_ok && cdiv64(P.M, 256) * cdiv64(P.N, 128) >= 128) {  // at least half the CUs
@@ -1156,7 +1162,7 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
         }
         return launch_gemm_t<AL, BL, 256>(P, stream);
     }
-    if (ring) return dllm_launch_gemm_ring(P, AL, stream);
+    if (ring) return dllm_launch_gemm_ring(P, AL, stream, V.ring_stages);
     return launch_gemm_t<AL, BL, 128>(P, stream);
 }
 

@@ -27,10 +27,11 @@
 
 namespace {
 
-constexpr int RING_NS = 4;                       // LDS stages
 constexpr int RING_TILE = 128 * BK * 2;          // one operand tile: 16 KiB
-constexpr int RING_STAGE = 2 * RING_TILE;        // A | B
-constexpr int RING_LDS = RING_NS * RING_STAGE;   // 128 KiB
+constexpr int RING_STAGE = 2 * RING_TILE;        // A | B: 32 KiB; the ring has NS = 4 stages (128 KiB, one block per CU) or NS = 2
+                                                 // (64 KiB, TWO blocks per CU: short reductions on multi-round grids, where a block's
+                                                 // prologue and epilogue would otherwise sit idle next to nothing -- [65536, 320, 320]
+                                                 // is 6 rounds of 5 K steps each)
 
 struct RingConv {
     int64_t pix_off[2];   // element offset of (img, oh*stride - pad, ow*stride - pad, 0) of the lane's row in each of the wave's 2 A groups
@@ -72,7 +73,7 @@ __device__ __forceinline__ void ring_conv_init(RingConv& d, const ConvGeom& g, i
 }
 
 // AL: A_K (k-contiguous rows), A_CONV (plain gather), A_CONVS (shift gather).  GLU: EPI_GEGLU column pairing (P.N = F outputs).
-template <int AL, bool GLU>
+template <int AL, bool GLU, int RING_NS = 4>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 128, BN_OUT = GLU ? 64 : 128, MI = 2, NG = 2 * MI;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
 
     // q-th DMA instruction (0, 1: A groups; 2, 3: B groups) of the stage whose K tile starts at element k0, into ring slot `slot`
     auto issue_one = [&](int64_t k0, int slot, int q) {
-        char* st = smem + slot * RING_STAGE;
+        char* st = smem + slot * RING_STAGE;   // (slot < RING_NS)
         if (q < 2) {
             const bf16* src;
             if constexpr (!CONV) {
@@ -191,9 +192,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
             for (int q = 0; q < 4; ++q) issue_one((int64_t)(kt0 + s) * BK, s, q);
             conv_advance();
         }
-        if (pre >= 3)
+        if (RING_NS > 3 && pre >= 3)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (pre == 2)
+        else if (RING_NS > 2 && pre == 2)
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -232,9 +233,9 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
                         // stage t+1 must have landed (this wave's share; the barrier extends that to every wave's): the stages
                         // issued after it -- at most two -- stay in flight across the barrier
                         const int ahead = nt - 2 - t;
-                        if (ahead >= 2)
+                        if (RING_NS > 3 && ahead >= 2)
                             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                        else if (ahead == 1)
+                        else if (RING_NS > 2 && ahead >= 1)
                             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                         else
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -358,13 +359,22 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
 }
 
 template <int AL, bool GLU>
-int launch_ring_t(const GemmParams& P, hipStream_t stream) {
+int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream) {
     const int64_t tiles = cdiv64(P.M, 128) * cdiv64(P.N, GLU ? 64 : 128);
     if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
     static std::atomic<uint64_t> lds_ok{0};
-    dllm_ensure_dyn_lds(&gemm_ring_kernel<AL, GLU>, RING_LDS, lds_ok);
+    dllm_ensure_dyn_lds(&gemm_ring_kernel<AL, GLU, 4>, 4 * RING_STAGE, lds_ok);
     const int sk = P.splitk > 1 ? P.splitk : 1;
-    hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU>), dim3((unsigned)tiles, sk), dim3(512), RING_LDS, stream, P);
+    // Two stages, two blocks per CU, for grids with more blocks than CUs and K <= 2048: a block's prologue (first DMA round trip) and
+    // epilogue (residual loads, LDS staging, stores) then run next to the other block's K loop instead of next to nothing.  Measured
+    // at UNet batch 16 against the four-stage ring (profiles/r04_unet_gemm_b16_ring_stages.log): [65536, 320, 320] 35.7 -> 28.4 us,
+    // [65536, 2560, 320] 241 -> 194, [16384, 1920, 640] 70.8 -> 57.0, [4096, 10240, 1280] 172 -> 139 (the 256 x 256 pipelined tile:
+    // 152), K = 2560 / 5120 tie; on grids of at most one block per CU the deep ring wins ([1024, 1280, 1280] 13.2 vs 17.9 us).
+    const bool ns2 = two_stage > 0 || (two_stage == 0 && P.K <= 32 * BK && tiles * sk > (int64_t)dllm_num_cus());
+    if (ns2)
+        hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 2>), dim3((unsigned)tiles, sk), dim3(512), 2 * RING_STAGE, stream, P);
+    else
+        hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 4>), dim3((unsigned)tiles, sk), dim3(512), 4 * RING_STAGE, stream, P);
     if (sk > 1 && P.counters == nullptr) {
         const int64_t work = P.M * (P.N >> 2);
         const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
@@ -377,16 +387,17 @@ int launch_ring_t(const GemmParams& P, hipStream_t stream) {
 
 // Preconditions (checked by the caller, gemm.hip: ring_ok): K % 64 == 0, K >= 64, B k-contiguous, conv: C % 64 == 0;
 // EPI_GEGLU: P.N = F with F % 64 == 0, no split-K, bf16 output, no residual / per-image bias.
-int dllm_launch_gemm_ring(const GemmParams& P, int layout_a, hipStream_t stream) {
+// two_stage: 0 automatic, 1 force the two-stage ring (two blocks per CU), -1 force the four-stage ring
+int dllm_launch_gemm_ring(const GemmParams& P, int layout_a, hipStream_t stream, int two_stage) {
     if (P.epi == EPI_GEGLU) {
         if (layout_a != A_K || P.splitk > 1 || (P.N & 63) || P.out_f32 || P.residual != nullptr || P.rg_bias != nullptr || P.accumulate)
             return DLLM_ERR_SHAPE;
-        return launch_ring_t<A_K, true>(P, stream);
+        return launch_ring_t<A_K, true>(P, two_stage, stream);
     }
-    if (layout_a == A_K) return launch_ring_t<A_K, false>(P, stream);
+    if (layout_a == A_K) return launch_ring_t<A_K, false>(P, two_stage, stream);
     if (layout_a == A_CONV) {
-        if (P.cv.up_shift | P.cv.even_only) return launch_ring_t<A_CONVS, false>(P, stream);
-        return launch_ring_t<A_CONV, false>(P, stream);
+        if (P.cv.up_shift | P.cv.even_only) return launch_ring_t<A_CONVS, false>(P, two_stage, stream);
+        return launch_ring_t<A_CONV, false>(P, two_stage, stream);
     }
     return DLLM_ERR_SHAPE;
 }

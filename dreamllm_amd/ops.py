@@ -71,6 +71,8 @@ GEMM_VARIANT = 0
 # A/B knob (tools, bench): DREAMLLM_GEMM_NO_RING=1 sets bit 25 of `variant` on every automatic call: the library then never picks the
 # ring-buffered 128 x 128 kernel by itself (round 3's kernel selection), so one process can time both selections on one box.
 GEMM_NO_RING = (1 << 25) if os.environ.get("DREAMLLM_GEMM_NO_RING", "0") == "1" else 0
+# DREAMLLM_RING_4STAGE=1: bit 27, the ring kernel never takes its two-stage (two blocks per CU) form (A/B knob)
+GEMM_NO_RING |= (1 << 27) if os.environ.get("DREAMLLM_RING_4STAGE", "0") == "1" else 0
 
 
 # Attention kernel choice handed to dllm_attn_fwd / dllm_attn_bwd in bits 1-2 of `causal` (include/dreamllm_hip.h): 0 automatic,
@@ -297,8 +299,8 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
         if gm == 0 and GEMM_TUNE_GROUP_M and 2.0 * M * N * K >= _TUNE_MIN_FLOPS:   # opt-in tool, off in the product path
             gm = _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha)
         variant = (gm << 16) | persist
-    if (variant & 0xffff) == 0 and epi != "geglu":
-        variant |= GEMM_NO_RING
+    if (variant & 0xffff) == 0:
+        variant |= GEMM_NO_RING if epi != "geglu" else (GEMM_NO_RING & (1 << 27))
     with _GemmTimer((4.0 if epi == "geglu" else 2.0) * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
         check("dllm_gemm_bf16_splitk", _p(a), _p(b), _p(out), _p(bias), _p(residual), M, N, K, lda, ldb, out.stride(0),
               ldr if residual is not None else 0, layout_a, layout_b, EPI[epi], _dt(out), int(accumulate), float(alpha),

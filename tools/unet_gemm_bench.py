@@ -127,6 +127,8 @@ def main():
         res["old128"] = run_linear(M, N, K, 128, hint)
         for sk in cands:
             res[f"ring/sk{sk}"] = run_linear(M, N, K, 264, sk)
+        res["ring4st"] = run_linear(M, N, K, 267, 1)   # four-stage ring forced (one block per CU)
+        res["ring2st"] = run_linear(M, N, K, 268, 1)   # two-stage ring forced (two blocks per CU)
         if -(-M // 256) * -(-N // 256) >= 32:
             res["pipe256"] = run_linear(M, N, K, 259, 1)
         if tag == "ff1":
@@ -134,6 +136,7 @@ def main():
         best_ring = min(v for k, v in res.items() if k.startswith("ring/"))
         acc("auto", cnt, res["auto"]); acc("old128", cnt, res["old128"]); acc("ring_hint", cnt, res[f"ring/sk{hint}"]); acc("ring_best", cnt, best_ring)
         acc("best_any", cnt, min(v for k, v in res.items() if k != "ring+geglu"))
+        acc("ring4st", cnt, res["ring4st"]); acc("ring2st", cnt, res["ring2st"])
         fl = 2.0 * M * N * K
         print(f"x{cnt:2d} lin {tag:22s} M={M:6d} N={N:5d} K={K:5d} hint={hint:2d} | " +
               " ".join(f"{k}={v:6.1f}" for k, v in res.items()) + f" | best {fl / min(res.values()) / 1e6:6.1f} TF", flush=True)
@@ -155,6 +158,7 @@ def main():
         best_ring = min(v for k_, v in res.items() if k_.startswith("ring/"))
         acc("auto", cnt, res["auto"]); acc("old128", cnt, res["old128"]); acc("ring_hint", cnt, res[f"ring/sk{hint}"]); acc("ring_best", cnt, best_ring)
         acc("best_any", cnt, min(res.values()))
+        acc("ring4st", cnt, 0.0); acc("ring2st", cnt, 0.0)
         fl = 2.0 * M * CO * K
         print(f"x{cnt:2d} conv {H:2d}x{H:<2d} C{C:4d}->{CO:4d} k{k} s{stride} up{up} M={M:6d} K={K:5d} hint={hint:2d} | " +
               " ".join(f"{k_}={v:6.1f}" for k_, v in res.items()) + f" | best {fl / min(res.values()) / 1e6:6.1f} TF", flush=True)
