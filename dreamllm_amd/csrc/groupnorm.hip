@@ -295,6 +295,12 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
             }
             ok = spin < (1 << 15);
         }
+        // Ordering: the partners' sums are read with agent-scope atomic loads (served by memory, not by this XCD's
+        // non-coherent L2 lines) issued after the epoch load that ended the spin; VMEM loads of one wave return in order and the
+        // publishers drained their stores (vmcnt(0)) before taking the ticket.  The compiler barrier pins the program order of the
+        // relaxed loads.  A formal acquire here would emit `buffer_inv sc1` and drop the slice of x this block is about to
+        // re-read for the apply pass from L2 -- the reason the protocol is built from relaxed agent-scope atomics.
+        asm volatile("" ::: "memory");
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int q = 0; q < S; ++q) {

@@ -495,7 +495,19 @@ class StableDiffusionHead(MultimodalHead):
         # everything that depends on the timestep only (sinusoid, time-embedding MLP, every ResBlock's time_emb_proj: ~38 tiny
         # launches per step) is computed for ALL steps here, one GEMM per ResBlock; the captured forward reads one row of it
         addk = None if added_cond_kwargs is None else {k: v.to(dev) for k, v in added_cond_kwargs.items()}
-        tb_table = self.unet.precompute_time_bias([float(t) for t in timesteps], 2 * B, addk)
+        # ONE host conversion of the schedule (a device tensor would cost a sync per element); without micro-conditioning the table
+        # depends on (schedule, batch) only and is kept across calls
+        ts_host = tuple(float(t) for t in (timesteps.tolist() if torch.is_tensor(timesteps) else timesteps))
+        # (weights replaced in place -- load_state_dict, .to() -- bump the tensor version / identity and drop the table)
+        w_sig = tuple((id(p), p._version) for p in self.unet.time_embedding.parameters()) + \
+            tuple((id(r.time_emb_proj.weight), r.time_emb_proj.weight._version) for r in self.unet._resnets())
+        tb_key = (ts_host, 2 * B, w_sig)
+        tb_cache = getattr(self, "_time_bias_cache", None)
+        if addk is None and tb_cache is not None and tb_cache[0] == tb_key:
+            tb_table = tb_cache[1]
+        else:
+            tb_table = self.unet.precompute_time_bias(list(ts_host), 2 * B, addk)
+            self._time_bias_cache = (tb_key, tb_table) if addk is None else None
         if ent is None:
             x_in = torch.zeros(2 * B, H, W, 8, dtype=self.dtype, device=dev)
             tb_static = tb_table[0].clone()
@@ -523,7 +535,7 @@ class StableDiffusionHead(MultimodalHead):
         x_in.zero_()
         x_in[:B, ..., :4] = lat.to(self.dtype)
         x_in[B:, ..., :4] = lat.to(self.dtype)
-        for i, t in enumerate(timesteps):
+        for i, t in enumerate(ts_host):  # host floats: no per-step device read of the schedule
             ent["tb"].copy_(tb_table[i])
             ent["graph"].replay()
             sched.step_cfg_fused_(ent["pred"], t, lat, x_in, guidance_scale)

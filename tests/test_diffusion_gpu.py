@@ -433,3 +433,36 @@ def test_sdxl_head_dummy_forward_config_and_state_dict(golden, tmp_path):
     head.load_model(str(tmp_path))
     assert torch.equal(head.global_projector.projector.weight.data, w)
     assert head.fsdp_ignored_modules() == [head.vae, head.unet]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sdxl", [False, True])
+def test_unet_precomputed_time_bias_matches_per_step(sdxl):
+    """The denoising loop's table of everything that depends on the timestep only (`precompute_time_bias`: one GEMM per ResBlock
+    over M = steps rows) against the per-call path (the same GEMMs over M = N rows inside every forward, as diffusers does,
+    modeling_plugins.py:809-821): the two may pick different split-K factors, so the bf16 biases agree to rounding, not bit for
+    bit -- the noise prediction must stay far inside the model-level yard-stick."""
+    cfg, sd, m = _unet_pair(sdxl)
+    torch.manual_seed(8)
+    N = 2
+    x = torch.randn(N, 4, 16, 16, device=DEV, dtype=BF)
+    ctx = torch.randn(N, 8, 64, device=DEV, dtype=BF)
+    added = dict(text_embeds=torch.randn(N, 40, device=DEV, dtype=BF),
+                 time_ids=torch.tensor([[16., 16, 0, 0, 16, 16]] * N, device=DEV)) if sdxl else None
+    steps = [981.0, 741.0, 501.0, 21.0]
+    with torch.no_grad():
+        table = m.precompute_time_bias(steps, N, added)
+        assert table.shape == (len(steps), m.time_bias_layout(N)[1]) and table.dtype == BF
+        for i, t in enumerate(steps):
+            a = m(x, int(t), ctx, added_cond_kwargs=added).sample
+            b = m(x, None, ctx, time_bias=table[i]).sample
+            assert rel_l2(b, a) < 4e-3, (sdxl, t, rel_l2(b, a))
+    # the table row IS the per-call bias up to bf16 GEMM rounding
+    with torch.no_grad():
+        emb_act = m._embedding(torch.tensor([steps[1]] * N, device=DEV), N, added)
+        from dreamllm_amd import ops
+        emb_act = ops.silu(emb_act)
+        offs, _ = m.time_bias_layout(N)
+        for r, (o, c) in zip(m._resnets(), offs):
+            per_call = r.time_emb_proj(emb_act)
+            assert rel_l2(table[1][o:o + N * c].view(N, c), per_call) < 4e-3
