@@ -1046,8 +1046,9 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
             const double kt = (double)(P.K / BK);
             const bool conv = AL == A_CONV;
             const int64_t tiles128 = cdiv64(P.M, 128) * cdiv64(P.N, 128);
-            // (grids of more than one block per CU with K <= 2048 run the two-stage ring, two blocks per CU: 2.3 + 0.48 k per round)
-            const bool two_stage = V.ring_stages >= 0 && tiles128 > 256 && P.K <= 32 * BK;
+            // (grids of more than one block per CU run the two-stage ring, two blocks per CU -- linears up to K = 2048, conv gathers at
+            // any K: 2.3 + 0.48 k (conv 0.6 k) per round; the figures reproduce the batch-16 conv table to 1-3 %)
+            const bool two_stage = V.ring_stages >= 0 && tiles128 > 256 && (P.K <= 32 * BK || conv);
             const double t_ring = (double)cdiv64(tiles128, 256) * (two_stage ? 2.3 + kt * (conv ? 0.6 : 0.48) : 3.2 + kt * (conv ? 0.71 : 0.57));
             const double t_n128 = (double)cdiv64(cdiv64(P.M, 256) * cdiv64(P.N, 128), 256) * (14.0 + kt * 1.13);
             const double t_256 = (double)cdiv64(tiles256, 256) * (27.0 + kt * 1.5);

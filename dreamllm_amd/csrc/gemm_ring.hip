@@ -370,7 +370,9 @@ int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream) {
     // at UNet batch 16 against the four-stage ring (profiles/r04_unet_gemm_b16_ring_stages.log): [65536, 320, 320] 35.7 -> 28.4 us,
     // [65536, 2560, 320] 241 -> 194, [16384, 1920, 640] 70.8 -> 57.0, [4096, 10240, 1280] 172 -> 139 (the 256 x 256 pipelined tile:
     // 152), K = 2560 / 5120 tie; on grids of at most one block per CU the deep ring wins ([1024, 1280, 1280] 13.2 vs 17.9 us).
-    const bool ns2 = two_stage > 0 || (two_stage == 0 && P.K <= 32 * BK && tiles * sk > (int64_t)dllm_num_cus());
+    // Conv gathers keep winning beyond K = 2048 (profiles/r04_unet_conv_b16_ring_stages.log, batch 16: [65536, 320, 2880] 238 -> 175 us
+    // against 193 for the 256 x 256 pipelined tile, [4096, 1280, 11520] 252 -> 221, [16384, 320, 2880] stride 2 72 -> 58): no K limit there.
+    const bool ns2 = two_stage > 0 || (two_stage == 0 && (P.K <= 32 * BK || AL != A_K) && tiles * sk > (int64_t)dllm_num_cus());
     if (ns2)
         hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 2>), dim3((unsigned)tiles, sk), dim3(512), 2 * RING_STAGE, stream, P);
     else

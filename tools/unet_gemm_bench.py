@@ -22,6 +22,7 @@ BF = torch.bfloat16
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 NB = int(args[0]) if args else 2
 QUICK = "--quick" in sys.argv
+CONVS_ONLY = "--convs-only" in sys.argv
 REPS = 20
 
 # transformer linears per level: (blocks, HW, C)
@@ -120,7 +121,7 @@ def main():
         tot[name] = tot.get(name, 0.0) + cnt * us
 
     print(f"# UNet batch {NB}: linears")
-    for cnt, M, N, K, tag in LINEARS:
+    for cnt, M, N, K, tag in ([] if CONVS_ONLY else LINEARS):
         hint, cands = sk_candidates(M, N, K)
         res = {}
         res["auto"] = run_linear(M, N, K, 0, hint)
@@ -155,14 +156,16 @@ def main():
         if -(-M // 256) * -(-CO // 256) >= 32:
             res["pipe256"] = run_conv(NB, H, C, CO, k, stride, up, 259, 1)
             res["pipe256x128"] = run_conv(NB, H, C, CO, k, stride, up, 262, 1)
+        res["ring4st"] = run_conv(NB, H, C, CO, k, stride, up, 267, 1)
+        res["ring2st"] = run_conv(NB, H, C, CO, k, stride, up, 268, 1)
         best_ring = min(v for k_, v in res.items() if k_.startswith("ring/"))
         acc("auto", cnt, res["auto"]); acc("old128", cnt, res["old128"]); acc("ring_hint", cnt, res[f"ring/sk{hint}"]); acc("ring_best", cnt, best_ring)
         acc("best_any", cnt, min(res.values()))
-        acc("ring4st", cnt, 0.0); acc("ring2st", cnt, 0.0)
+        acc("ring4st", cnt, res["ring4st"]); acc("ring2st", cnt, res["ring2st"])
         fl = 2.0 * M * CO * K
         print(f"x{cnt:2d} conv {H:2d}x{H:<2d} C{C:4d}->{CO:4d} k{k} s{stride} up{up} M={M:6d} K={K:5d} hint={hint:2d} | " +
               " ".join(f"{k_}={v:6.1f}" for k_, v in res.items()) + f" | best {fl / min(res.values()) / 1e6:6.1f} TF", flush=True)
-    print("# convs, us per forward: " + " ".join(f"{k}={tot[k] - lin_tot[k]:8.1f}" for k in tot), flush=True)
+    print("# convs, us per forward: " + " ".join(f"{k}={tot[k] - lin_tot.get(k, 0.0):8.1f}" for k in tot), flush=True)
     print("# all GEMM-shaped launches, us per forward: " + " ".join(f"{k}={v:8.1f}" for k, v in tot.items()), flush=True)
 
 
