@@ -403,6 +403,33 @@ class _MaskHasHoles(ValueError):
     """A 2-D mask whose valid tokens are not one contiguous run per row (see `_mask_to_spans`)."""
 
 
+def _mask4d_to_2d(mask4d):
+    """[B, 1, Sq, Sk] mask in the format the reference's eager attention receives from `_prepare_4d_causal_attention_mask`
+    (modeling_dreamllm.py:35,965-967: additive, 0 = attend / dtype-min = masked; a boolean "attend" mask is accepted too) -> the 2-D key
+    mask [B, Sk] it was built from.  Only the form the reference itself builds is representable on the flash path -- causal over
+    the (past + new) keys AND key padding: the newest query row sees every valid key, so it IS the key mask; the other rows are
+    checked against causal & key-mask (rows whose own token is padding are not compared: their content differs between
+    transformers versions and their output is discarded).  Anything else (bidirectional, sliding window, arbitrary biases)
+    raises ValueError; nothing is silently approximated."""
+    if mask4d.dim() != 4 or mask4d.shape[1] != 1:
+        raise ValueError(f"attention_mask must be [B, Sk] or [B, 1, Sq, Sk], got {tuple(mask4d.shape)}")
+    allowed = mask4d[:, 0] if mask4d.dtype == torch.bool else (mask4d[:, 0] == 0)
+    B, Sq, Sk = allowed.shape
+    if Sk < Sq:
+        raise ValueError("4-D attention_mask: fewer keys than queries")
+    key_valid = allowed[:, -1, :]
+    if not (allowed.is_cuda and torch.cuda.is_current_stream_capturing()):
+        past = Sk - Sq
+        qi = torch.arange(Sq, device=allowed.device)[:, None] + past
+        causal = torch.arange(Sk, device=allowed.device)[None, :] <= qi
+        expect = causal[None] & key_valid[:, None, :]
+        q_valid = key_valid[:, past:]
+        if not bool(((allowed == expect) | ~q_valid[:, :, None]).all()):
+            raise ValueError("a 4-D attention_mask is supported in the form the reference builds (causal + key padding, "
+                             "_prepare_4d_causal_attention_mask); other patterns cannot run on the flash-attention path")
+    return key_valid.to(torch.long)
+
+
 def _mask_to_spans(attention_mask, q_len=None):
     """2-D padding mask [B, Sk] -> (seqstart, seqlens): int32 [B] device tensors (or None) describing the ONE contiguous run
     of valid tokens of every row, which is what the flash kernels take instead of the reference's unpad / pad round trip
@@ -416,13 +443,18 @@ def _mask_to_spans(attention_mask, q_len=None):
     A mask with holes or more than one run cannot be expressed as a span and raises `_MaskHasHoles` (a ValueError):
     `DreamLLMModel._forward` then takes the compaction path (valid tokens gathered to the front in order, original positions kept
     for RoPE -- what `_upad_input` / `pad_input` do around the reference's flash kernel, modeling_dreamllm.py:523-545,553-583);
-    silently attending to pad tokens is never an option.  A 4-D additive mask is rejected.  The check reads
+    silently attending to pad tokens is never an option.  A 4-D mask in the reference's eager format (causal + key padding) is
+    reduced to its key mask first (`_mask4d_to_2d`); any other 4-D pattern is rejected.  The check reads
     one flag back from the device (skipped under stream capture); callers that already know the spans pass
     `seqlens=` / `seqstart=` instead of a mask and stay sync-free (bench.py, data.collate_interleaved)."""
     if attention_mask is None:
         return None, None
+    if attention_mask.dim() == 4:   # the reference's eager-path format: recover the key mask it was built from
+        if q_len is None:
+            q_len = attention_mask.shape[2]
+        attention_mask = _mask4d_to_2d(attention_mask)
     if attention_mask.dim() != 2:
-        raise ValueError("the HIP decoder takes a 2-D padding mask (flash-attention path); 4-D additive masks are not supported")
+        raise ValueError(f"attention_mask must be [B, Sk] or [B, 1, Sq, Sk], got {tuple(attention_mask.shape)}")
     m = attention_mask != 0
     B, Sk = m.shape
     lens = m.sum(dim=-1, dtype=torch.int32)
@@ -767,6 +799,10 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
             if attention_mask.shape[-1] != seq_length + past_len:
                 raise ValueError(f"attention_mask covers {attention_mask.shape[-1]} positions, expected past + new = "
                                  f"{past_len} + {seq_length} (modeling_dreamllm.py:960-967)")
+            if attention_mask.dim() == 4:   # the eager-path format (modeling_dreamllm.py:965-967) -> the key mask it was built from
+                if attention_mask.shape[2] != seq_length:
+                    raise ValueError(f"4-D attention_mask has {attention_mask.shape[2]} query rows, expected {seq_length}")
+                attention_mask = _mask4d_to_2d(attention_mask)
             try:
                 seqstart, seqlens = _mask_to_spans(attention_mask, q_len=seq_length)  # once per forward, not per layer
             except _MaskHasHoles:

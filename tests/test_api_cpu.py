@@ -372,4 +372,49 @@ def test_unet_time_bias_layout_and_mask_span_errors():
         _mask_to_spans(am2)
     assert issubclass(_MaskHasHoles, ValueError)
     with pytest.raises(ValueError):
-        _mask_to_spans(torch.zeros(2, 1, 4, 4))
+        _mask_to_spans(torch.zeros(2, 1, 4, 4))      # 4-D, not causal: not representable on the flash path
+
+
+def test_4d_causal_mask_reduces_to_the_same_spans_as_its_2d_mask():
+    """The reference's eager attention receives `_prepare_4d_causal_attention_mask(mask_2d, ...)` (modeling_dreamllm.py:35,965-967).
+    A caller that hands that 4-D mask to the HIP decoder gets exactly the spans of the 2-D mask it was built from -- right padding,
+    left padding, with a KV cache, boolean form -- and any 4-D pattern that is not causal + key padding raises."""
+    import warnings
+    import pytest
+    from dreamllm_amd.modeling_dreamllm import _mask4d_to_2d, _mask_to_spans
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        from transformers.modeling_attn_mask_utils import _prepare_4d_causal_attention_mask as prep
+
+        def same(a, b):
+            return all((x is None and y is None) or (x is not None and y is not None and torch.equal(x, y)) for x, y in zip(a, b))
+
+        B, S = 3, 10
+        x = torch.zeros(B, S, 8)
+        right = torch.ones(B, S, dtype=torch.long)
+        right[1, 7:] = 0
+        left = torch.ones(B, S, dtype=torch.long)
+        left[0, :3] = 0
+        left[2, :1] = 0
+        for m2 in (right, left):
+            m4 = prep(m2, (B, S), x, 0)
+            assert m4.shape == (B, 1, S, S)
+            assert torch.equal(_mask4d_to_2d(m4), m2)
+            assert same(_mask_to_spans(m4), _mask_to_spans(m2))
+            assert same(_mask_to_spans(m4 == 0), _mask_to_spans(m2))          # boolean "attend" form
+            assert same(_mask_to_spans(m4.to(torch.bfloat16)), _mask_to_spans(m2))
+        past = 6
+        cache = torch.ones(B, S + past, dtype=torch.long)
+        cache[2, :4] = 0
+        m4 = prep(cache, (B, S), x, past)
+        assert m4.shape == (B, 1, S, S + past)
+        assert same(_mask_to_spans(m4), _mask_to_spans(cache, q_len=S))
+    bidir = torch.zeros(B, 1, S, S)                                           # everything attends: not causal
+    with pytest.raises(ValueError):
+        _mask_to_spans(bidir)
+    window = prep(right, (B, S), x, 0).clone()
+    window[:, :, 5, 0] = torch.finfo(torch.float32).min                       # a sliding-window-like hole in a valid row
+    with pytest.raises(ValueError):
+        _mask_to_spans(window)
+    with pytest.raises(ValueError):
+        _mask_to_spans(torch.zeros(B, 2, S, S))                               # per-head masks

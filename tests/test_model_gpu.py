@@ -81,6 +81,17 @@ def test_model_forward_padding_golden(golden):
         e_ref = rel_l2(ob[b, :n], g["out"][b, :n])
         e = rel_l2(out[b, :n], g["out"][b, :n])
         assert e <= _bound(e_ref), (b, e, e_ref)
+    # the reference's eager-path mask format (4-D additive, modeling_dreamllm.py:965-967) reduces to the same spans: same launches,
+    # bit-identical output -- through the model and through a direct DreamLLMDecoderLayer.forward call
+    B, S = am.shape
+    m4 = llm_ref.causal_mask_4d(am, B, S, torch.float32).to(DEV)
+    with torch.no_grad():
+        out4 = model._forward(inputs_embeds=g["emb"].to(BF).to(DEV), attention_mask=m4, use_cache=False).last_hidden_state
+        assert torch.equal(out4, out)
+        x = g["emb"].to(BF).to(DEV)
+        y2 = model.layers[0](x, attention_mask=am.to(DEV))[0]
+        y4 = model.layers[0](x, attention_mask=m4.to(BF))[0]
+        assert torch.equal(y4, y2)
 
 
 class _FakeDream(nn.Module):
