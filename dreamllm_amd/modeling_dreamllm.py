@@ -424,7 +424,9 @@ def _mask4d_to_2d(mask4d):
         causal = torch.arange(Sk, device=allowed.device)[None, :] <= qi
         expect = causal[None] & key_valid[:, None, :]
         q_valid = key_valid[:, past:]
-        if not bool(((allowed == expect) | ~q_valid[:, :, None]).all()):
+        # additive form: entries are 0 (attend) or a large negative (dtype-min / -inf); anything else is a bias, not a mask
+        is_mask = True if mask4d.dtype == torch.bool else bool(((mask4d == 0) | (mask4d <= -1e4)).all())
+        if not is_mask or not bool(((allowed == expect) | ~q_valid[:, :, None]).all()):
             raise ValueError("a 4-D attention_mask is supported in the form the reference builds (causal + key padding, "
                              "_prepare_4d_causal_attention_mask); other patterns cannot run on the flash-attention path")
     return key_valid.to(torch.long)
