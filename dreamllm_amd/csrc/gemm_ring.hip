@@ -73,24 +73,14 @@ __device__ __forceinline__ void ring_conv_init(RingConv& d, const ConvGeom& g, i
 }
 
 // AL: A_K (k-contiguous rows), A_CONV (plain gather), A_CONVS (shift gather).  GLU: EPI_GEGLU column pairing (P.N = F outputs).
-// KSPLIT (experiment, tile code 270): the two halves of the block split every 64-deep K tile -- waves 0-3 take its first 32-deep k
-// step, waves 4-7 the second -- on 2 x 2 wave tiles of 64 x 64: a wave then reads 4 A + 4 B fragments per 16 MFMAs instead of
-// 2 x (2 + 4) = 12 (LDS fragment traffic -33 %); after the K loop the partner waves (w, w ^ 4) exchange the half of their 64 x 64
-// partial sums the other one finalises through the idle ring and every wave leaves with the same 32 x 64 tile shape the epilogues
-// below expect.
-template <int AL, bool GLU, int RING_NS = 4, bool KSPLIT = false>
-__global__ __launch_bounds__(512, (RING_NS == 2 && KSPLIT) ? 4 : 2) void gemm_ring_kernel(GemmParams P) {
+template <int AL, bool GLU, int RING_NS = 4>
+__global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    static_assert(!(GLU && KSPLIT), "the GEGLU column pairing keeps the 4 x 2 wave grid");
     constexpr int BM = 128, BN_OUT = GLU ? 64 : 128, MI = 2, NG = 2 * MI;
     constexpr bool CONV = (AL == A_CONV || AL == A_CONVS), SHIFT = (AL == A_CONVS);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // K loop: wave tile origin (wmk, wn); epilogue: the wave's final 32 x 64 tile at (wm, wn)
-    const int kg = KSPLIT ? (wave >> 2) : 0;
-    const int wmk = KSPLIT ? ((wave >> 1) & 1) * 64 : (wave >> 1) * 32;
-    const int wn = (wave & 1) * 64;
-    const int wm = KSPLIT ? wmk + kg * 32 : wmk;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
 
     // XCD-aware grouped tile order (the hardware deals consecutive blocks to the 8 XCDs round-robin)
     const int num_pid_m = (int)((P.M + BM - 1) / BM), num_pid_n = (int)((P.N + BN_OUT - 1) / BN_OUT);
@@ -126,11 +116,6 @@ __global__ __launch_bounds__(512, (RING_NS == 2 && KSPLIT) ? 4 : 2) void gemm_ri
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 acck[KSPLIT ? 4 : 1][4];   // KSPLIT: the wave's 64 x 64 partial sums over its k steps
-#pragma unroll
-    for (int i = 0; i < (KSPLIT ? 4 : 1); ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acck[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- per-lane DMA sources: the wave's two 8-row groups of each operand tile -------------------------------------------
     const bf16* a_src[2];
@@ -217,153 +202,61 @@ __global__ __launch_bounds__(512, (RING_NS == 2 && KSPLIT) ? 4 : 2) void gemm_ri
 
         const int lg = lane >> 4, lt = lane & 15;
         const uint32_t s0 = lds_addr(smem);
-        if constexpr (KSPLIT) {
-            // fragment of k step kg: chunk (4 kg + lg) ^ swizzle = (lg ^ swizzle) ^ 4 kg -> byte offset ^ (kg << 6)
-            const uint32_t offA = (uint32_t)kc_off(wmk + lt, lg) ^ (uint32_t)(kg << 6);
-            const uint32_t offB = (uint32_t)RING_TILE + ((uint32_t)kc_off(wn + lt, lg) ^ (uint32_t)(kg << 6));
-            FragR<false> fa[2];
-            FragR<false> fb[2][4];   // the B fragments serve all four groups of a tile: the next tile's go to the other set
-            uint32_t ab = s0 + offA, bb = s0 + offB;
-            auto first_reads = [&](auto parc) {
-                constexpr int par = decltype(parc)::value;
-                static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, 0>(fb[par][decltype(j)::value], bb); });
-                fragr_issue<false, 0, 0>(fa[0], ab);
-            };
-            first_reads(std::integral_constant<int, 0>{});
-            auto tile_body = [&](auto parc, int t) {
-                constexpr int par = decltype(parc)::value;
-                const bool pf = t + (RING_NS - 1) < nt;
-                const int64_t kpf = (int64_t)(kt0 + t + (RING_NS - 1)) * BK;
-                const int pslot = (t + (RING_NS - 1)) & (RING_NS - 1);
-                static_for<0, 4>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value;
-                    if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
-                    if constexpr (g < 3) {
-                        fragr_issue<false, g + 1, 0>(fa[(g + 1) & 1], ab);
-                        fragr_wait<1>(fa[g & 1]);
-                    } else {
-                        fragr_wait<0>(fa[g & 1]);
-                        if (t + 1 < nt) {
-                            const int ahead = nt - 2 - t;
-                            if (RING_NS > 3 && ahead >= 2)
-                                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                            else if (RING_NS > 2 && ahead >= 1)
-                                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                            else
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_s_barrier();
-                            const uint32_t so = (uint32_t)(((t + 1) & (RING_NS - 1)) * RING_STAGE);
-                            ab = s0 + offA + so;
-                            bb = s0 + offB + so;
-                            first_reads(std::integral_constant<int, par ^ 1>{});
-                        }
-                    }
-                    if constexpr (g == 0) static_for<0, 4>([&](auto j) { fragr_touch(fb[par][decltype(j)::value]); });
-                    const bf16x8 va = fragr_value(fa[g & 1]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acck[g][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[par][j]), va, acck[g][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                if (pf) conv_advance();
-            };
-            for (int t = 0; t < nt; t += 2) {
-                tile_body(std::integral_constant<int, 0>{}, t);
-                if (t + 1 < nt) tile_body(std::integral_constant<int, 1>{}, t + 1);
-            }
-        } else {
-            const uint32_t offA = (uint32_t)kc_off(wm + lt, lg);
-            const uint32_t offB = (uint32_t)RING_TILE + (uint32_t)kc_off(wn + lt, lg);
-            FragR<false> fa[2];
-            FragR<false> fb[2][4];
-            uint32_t ab = s0 + offA, bb = s0 + offB;
-            auto first_reads = [&]() {
-                static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, 0>(fb[0][decltype(j)::value], bb); });
-                fragr_issue<false, 0, 0>(fa[0], ab);
-            };
-            first_reads();
+        const uint32_t offA = (uint32_t)kc_off(wm + lt, lg);
+        const uint32_t offB = (uint32_t)RING_TILE + (uint32_t)kc_off(wn + lt, lg);
+        FragR<false> fa[2];
+        FragR<false> fb[2][4];
+        uint32_t ab = s0 + offA, bb = s0 + offB;
+        auto first_reads = [&]() {
+            static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, 0>(fb[0][decltype(j)::value], bb); });
+            fragr_issue<false, 0, 0>(fa[0], ab);
+        };
+        first_reads();
 
-            for (int t = 0; t < nt; ++t) {
-                // stage t+3 goes into the slot stage t-1 was read from: every wave finished those reads before the last barrier
-                const bool pf = t + (RING_NS - 1) < nt;
-                const int64_t kpf = (int64_t)(kt0 + t + (RING_NS - 1)) * BK;
-                const int pslot = (t + (RING_NS - 1)) & (RING_NS - 1);
-                static_for<0, NG>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
-                    if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
-                    if constexpr (g < NG - 1) {
-                        constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
-                        if constexpr (in == 0)
-                            static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, kn>(fb[kn][decltype(j)::value], bb); });
-                        fragr_issue<false, in, kn>(fa[(g + 1) & 1], ab);
-                        fragr_wait<1 + (in == 0 ? 4 : 0)>(fa[g & 1]);
-                    } else {
-                        fragr_wait<0>(fa[g & 1]);
-                        if (t + 1 < nt) {
-                            // stage t+1 must have landed (this wave's share; the barrier extends that to every wave's): the stages
-                            // issued after it -- at most two -- stay in flight across the barrier
-                            const int ahead = nt - 2 - t;
-                            if (RING_NS > 3 && ahead >= 2)
-                                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                            else if (RING_NS > 2 && ahead >= 1)
-                                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                            else
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_s_barrier();
-                            const uint32_t so = (uint32_t)(((t + 1) & (RING_NS - 1)) * RING_STAGE);
-                            ab = s0 + offA + so;
-                            bb = s0 + offB + so;
-                            first_reads();
-                        }
+        for (int t = 0; t < nt; ++t) {
+            // stage t+3 goes into the slot stage t-1 was read from: every wave finished those reads before the last barrier
+            const bool pf = t + (RING_NS - 1) < nt;
+            const int64_t kpf = (int64_t)(kt0 + t + (RING_NS - 1)) * BK;
+            const int pslot = (t + (RING_NS - 1)) & (RING_NS - 1);
+            static_for<0, NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
+                if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
+                if constexpr (g < NG - 1) {
+                    constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
+                    if constexpr (in == 0)
+                        static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, kn>(fb[kn][decltype(j)::value], bb); });
+                    fragr_issue<false, in, kn>(fa[(g + 1) & 1], ab);
+                    fragr_wait<1 + (in == 0 ? 4 : 0)>(fa[g & 1]);
+                } else {
+                    fragr_wait<0>(fa[g & 1]);
+                    if (t + 1 < nt) {
+                        // stage t+1 must have landed (this wave's share; the barrier extends that to every wave's): the stages
+                        // issued after it -- at most two -- stay in flight across the barrier
+                        const int ahead = nt - 2 - t;
+                        if (RING_NS > 3 && ahead >= 2)
+                            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else if (RING_NS > 2 && ahead >= 1)
+                            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        const uint32_t so = (uint32_t)(((t + 1) & (RING_NS - 1)) * RING_STAGE);
+                        ab = s0 + offA + so;
+                        bb = s0 + offB + so;
+                        first_reads();
                     }
-                    if constexpr (i == 0) static_for<0, 4>([&](auto j) { fragr_touch(fb[kk][decltype(j)::value]); });
-                    const bf16x8 va = fragr_value(fa[g & 1]);
+                }
+                if constexpr (i == 0) static_for<0, 4>([&](auto j) { fragr_touch(fb[kk][decltype(j)::value]); });
+                const bf16x8 va = fragr_value(fa[g & 1]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                if (pf) conv_advance();
-            }
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (pf) conv_advance();
         }
     }
 
-    if constexpr (KSPLIT) {
-        // partner waves (w, w ^ 4) hold the two k halves of the same 64 x 64 tile; wave kg finalises its rows [32 kg, 32 kg + 32): it
-        // publishes the OTHER two 16-row blocks (8 KiB, lane-linear: conflict-free) and adds the partner's copy of its own two
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // every wave is done with its fragment reads: the ring is free
-        f32x4 keep[2][4], send[2][4];
-        if (kg == 0) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    keep[ii][j] = acck[ii][j];
-                    send[ii][j] = acck[2 + ii][j];
-                }
-        } else {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    keep[ii][j] = acck[2 + ii][j];
-                    send[ii][j] = acck[ii][j];
-                }
-        }
-        char* xw = smem + wave * 8192 + lane * 16;
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(xw + (ii * 4 + j) * 1024) = send[ii][j];
-        __syncthreads();
-        const char* xr = smem + (wave ^ 4) * 8192 + lane * 16;
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[ii][j] = keep[ii][j] + *reinterpret_cast<const f32x4*>(xr + (ii * 4 + j) * 1024);
-        __syncthreads();   // the regions are reused below (staging / the split-K ticket)
-    }
     if constexpr (GLU) {
         // lane holds, for rows m = m0 + wm + 16 i + (lane & 15): hidden acc[i][0..1] and gate acc[i][2..3] of the output columns
         // n = n0 + 32 (wave & 1) + 16 j + 4 (lane >> 4) + 0..3, j = 0, 1
@@ -466,7 +359,7 @@ __global__ __launch_bounds__(512, (RING_NS == 2 && KSPLIT) ? 4 : 2) void gemm_ri
 }
 
 template <int AL, bool GLU>
-int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream, int ksplit = 0) {
+int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream) {
     const int64_t tiles = cdiv64(P.M, 128) * cdiv64(P.N, GLU ? 64 : 128);
     if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
     static std::atomic<uint64_t> lds_ok{0};
@@ -480,20 +373,7 @@ int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream, int ks
     // Conv gathers keep winning beyond K = 2048 (profiles/r04_unet_conv_b16_ring_stages.log, batch 16: [65536, 320, 2880] 238 -> 175 us
     // against 193 for the 256 x 256 pipelined tile, [4096, 1280, 11520] 252 -> 221, [16384, 320, 2880] stride 2 72 -> 58): no K limit there.
     const bool ns2 = two_stage > 0 || (two_stage == 0 && (P.K <= 32 * BK || AL != A_K) && tiles * sk > (int64_t)dllm_num_cus());
-    bool launched = false;
-    if constexpr (!GLU) {
-        if (ksplit) {
-            static std::atomic<uint64_t> ldsk_ok{0};
-            dllm_ensure_dyn_lds(&gemm_ring_kernel<AL, GLU, 4, true>, 4 * RING_STAGE, ldsk_ok);
-            if (ns2)
-                hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 2, true>), dim3((unsigned)tiles, sk), dim3(512), 2 * RING_STAGE, stream, P);
-            else
-                hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 4, true>), dim3((unsigned)tiles, sk), dim3(512), 4 * RING_STAGE, stream, P);
-            launched = true;
-        }
-    }
-    if (launched) {
-    } else if (ns2)
+    if (ns2)
         hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 2>), dim3((unsigned)tiles, sk), dim3(512), 2 * RING_STAGE, stream, P);
     else
         hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 4>), dim3((unsigned)tiles, sk), dim3(512), 4 * RING_STAGE, stream, P);
@@ -509,17 +389,17 @@ int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream, int ks
 
 // Preconditions (checked by the caller, gemm.hip: ring_ok): K % 64 == 0, K >= 64, B k-contiguous, conv: C % 64 == 0;
 // EPI_GEGLU: P.N = F with F % 64 == 0, no split-K, bf16 output, no residual / per-image bias.
-// two_stage: 0 automatic, 1 force the two-stage ring (two blocks per CU), -1 force the four-stage ring; ksplit: the K-split wave grid
-int dllm_launch_gemm_ring(const GemmParams& P, int layout_a, hipStream_t stream, int two_stage, int ksplit) {
+// two_stage: 0 automatic, 1 force the two-stage ring (two blocks per CU), -1 force the four-stage ring
+int dllm_launch_gemm_ring(const GemmParams& P, int layout_a, hipStream_t stream, int two_stage) {
     if (P.epi == EPI_GEGLU) {
         if (layout_a != A_K || P.splitk > 1 || (P.N & 63) || P.out_f32 || P.residual != nullptr || P.rg_bias != nullptr || P.accumulate)
             return DLLM_ERR_SHAPE;
         return launch_ring_t<A_K, true>(P, two_stage, stream);
     }
-    if (layout_a == A_K) return launch_ring_t<A_K, false>(P, two_stage, stream, ksplit);
+    if (layout_a == A_K) return launch_ring_t<A_K, false>(P, two_stage, stream);
     if (layout_a == A_CONV) {
-        if (P.cv.up_shift | P.cv.even_only) return launch_ring_t<A_CONVS, false>(P, two_stage, stream, ksplit);
-        return launch_ring_t<A_CONV, false>(P, two_stage, stream, ksplit);
+        if (P.cv.up_shift | P.cv.even_only) return launch_ring_t<A_CONVS, false>(P, two_stage, stream);
+        return launch_ring_t<A_CONV, false>(P, two_stage, stream);
     }
     return DLLM_ERR_SHAPE;
 }
