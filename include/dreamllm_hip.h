@@ -99,12 +99,15 @@ int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int la
  * from any thread on any stream): low 16 bits = tile family -- 0 automatic (what the product passes), 128 / 256 register-staged
  * tiles, 257 plain LDS-DMA 256-tile kernel, 259 software-pipelined LDS-DMA kernel (the automatic choice for eligible shapes);
  * 264 the ring-buffered 128 x 128 kernel for small grids (forward linears / NHWC convs with K % 64 == 0; the automatic choice
- * wherever the register-staged 128-tile kernel used to run; ineligible calls fall back to the automatic choice);
+ * wherever the register-staged 128-tile kernel used to run; ineligible calls fall back to the automatic choice), 267 / 268 the same
+ * kernel forced to its four-stage (one block per CU) / two-stage (two blocks per CU) form; 262 the 256 x 128 pipelined tile; 266 the
+ * MFMA 32x32x16 experiment (forward layout, plain epilogue);
  * bits 16-23 = GROUP_M of the grouped tile order (0 = per-layout default); bit 24 = XCD-synchronised persistent walk; bit 25 = never
  * choose the ring-buffered kernel automatically (round 3's selection, an A/B knob); bit 26 = "with splitk <= 1 my workspace is a
  * stream-K workspace of dllm_gemm_streamk_ws_bytes() bytes" -- without it a workspace passed with splitk <= 1 is IGNORED (round 4,
  * round 3 treated any non-NULL workspace as 128 MiB of slab space; a caller re-using its smaller split-K buffer with
- * splitk = 1 would have been written out of bounds).  Tests pass 128 / 256 / 257 / 259 / 262 / 264 to cover
+ * splitk = 1 would have been written out of bounds); bit 27 = the ring-buffered kernel never takes its two-stage form (A/B knob).
+ * Tests pass 128 / 256 / 257 / 259 / 262 / 264 to cover
  * every kernel family.  Anything else returns DLLM_ERR_SHAPE.  (A build with -DDLLM_BENCH_MODES additionally accepts the
  * wrong-result diagnostic modes 258 / 260 / 263 / 265 used by tools/; the shipped library does not contain them.) */
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
