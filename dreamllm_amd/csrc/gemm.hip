@@ -40,13 +40,12 @@ struct Variant {
                          // without the bit a workspace passed with splitk <= 1 is ignored, as before round 3 -- no unchecked 128 MiB writes)
     int ring_stages = 0;  // tile codes 267 / 268: force the four- / two-stage ring (0: the launcher decides)
     int no_ring = 0;     // bit 25: never pick the ring-buffered kernel by itself (the round-3 selection: A/B knob of tools / bench)
-    int ring16 = 0;        // tile code 272: the 16-wave form of the ring kernel (experiment)
     int force_mfma32 = 0;  // tile code 266: the MFMA 32x32x16 experiment (gemm_mfma32.hip) wherever it is eligible (tools)
 };
 static inline int parse_variant(int variant, Variant& v) {
     const int tile = variant & 0xffff;
     v.group_m = (variant >> 16) & 0xff;
-    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262 || tile == 264 || tile == 266 || tile == 267 || tile == 268 || tile == 272 || tile == 273 || tile == 274;
+    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262 || tile == 264 || tile == 266 || tile == 267 || tile == 268;
 #ifdef DLLM_BENCH_MODES
     ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265;
     v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
@@ -60,10 +59,7 @@ static inline int parse_variant(int variant, Variant& v) {
     v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 262 || tile == 263 || tile == 265);
     v.force_tile = tile >= 257 ? 256 : tile;
     v.force_n128 = tile == 262;
-    v.force_ring = tile == 264 || tile == 267 || tile == 268 || tile == 272 || tile == 273 || tile == 274;
-    v.ring16 = tile == 272 ? 1 : ((tile == 273 || tile == 274) ? 2 : 0);   // 273: deep fragment prefetch, four-stage; 274: two-stage
-    if (tile == 273) v.ring_stages = -1;
-    if (tile == 274) v.ring_stages = 1;   // 267: four-stage ring forced, 268: two-stage ring forced (tools)
+    v.force_ring = tile == 264 || tile == 267 || tile == 268;   // 267: four-stage ring forced, 268: two-stage ring forced (tools)
     if (tile == 267 || tile == 268) v.ring_stages = tile == 267 ? -1 : 1;
     v.force_mfma32 = tile == 266;
     if (v.force_ring) v.force_tile = 0;
@@ -1019,7 +1015,7 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     if (P.M <= 0 || P.N <= 0) return DLLM_OK;
     bool ring = ring_ok<AL, BL>(P);
     if (P.epi == EPI_GEGLU) return ring ? dllm_launch_gemm_ring(P, AL, stream, V.ring_stages) : DLLM_ERR_SHAPE;   // only the ring kernel pairs the columns
-    if (V.force_ring && ring) return dllm_launch_gemm_ring(P, AL, stream, V.ring_stages, V.ring16);
+    if (V.force_ring && ring) return dllm_launch_gemm_ring(P, AL, stream, V.ring_stages);
     if constexpr (AL == A_K && BL == B_K) {
         if (V.force_mfma32 && (P.M % 256) == 0 && (P.N % 256) == 0 && (P.K % BK) == 0 && P.K >= BK && !P.out_f32 && P.bias == nullptr &&
             P.residual == nullptr && P.rg_bias == nullptr && P.epi == 0 && !P.accumulate && P.splitk <= 1 && (P.ldc & 7) == 0 &&

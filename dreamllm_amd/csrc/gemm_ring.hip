@@ -73,11 +73,7 @@ __device__ __forceinline__ void ring_conv_init(RingConv& d, const ConvGeom& g, i
 }
 
 // AL: A_K (k-contiguous rows), A_CONV (plain gather), A_CONVS (shift gather).  GLU: EPI_GEGLU column pairing (P.N = F outputs).
-// DEEP (experiment, tile code 273): all twelve fragment reads of a K tile are requested up front -- the six of its first k step right
-// after the tile barrier (under the previous tile's last MFMA group), the six of the second at the start of the tile -- and every MFMA
-// waits with a counted lgkmcnt for exactly the fragment it consumes, instead of one A fragment requested one MFMA group (64 matrix
-// cycles) ahead: the shallow form stalls on the LDS round trip in every group (both waves of a SIMD in lockstep after the barrier).
-template <int AL, bool GLU, int RING_NS = 4, bool DEEP = false>
+template <int AL, bool GLU, int RING_NS = 4>
 __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 128, BN_OUT = GLU ? 64 : 128, MI = 2, NG = 2 * MI;
@@ -208,119 +204,56 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
         const uint32_t s0 = lds_addr(smem);
         const uint32_t offA = (uint32_t)kc_off(wm + lt, lg);
         const uint32_t offB = (uint32_t)RING_TILE + (uint32_t)kc_off(wn + lt, lg);
-        if constexpr (DEEP) {
-            // fragment sets of the two k steps: fbq[kk][j] (B, 16 columns each), faq[kk][i] (A, 16 rows each); request order inside a
-            // k step: B0, A0, B1, B2, B3, A1 -- the order the MFMAs below consume them (LDS returns in order)
-            FragR<false> faq[2][2];
-            FragR<false> fbq[2][4];
-            uint32_t ab = s0 + offA, bb = s0 + offB;
-            auto reads_kk = [&](auto kc) {
-                constexpr int kk = decltype(kc)::value;
-                fragr_issue<false, 0, kk>(fbq[kk][0], bb);
-                fragr_issue<false, 0, kk>(faq[kk][0], ab);
-                fragr_issue<false, 1, kk>(fbq[kk][1], bb);
-                fragr_issue<false, 2, kk>(fbq[kk][2], bb);
-                fragr_issue<false, 3, kk>(fbq[kk][3], bb);
-                fragr_issue<false, 1, kk>(faq[kk][1], ab);
-            };
-            reads_kk(std::integral_constant<int, 0>{});
-            for (int t = 0; t < nt; ++t) {
-                const bool pf = t + (RING_NS - 1) < nt;
-                const int64_t kpf = (int64_t)(kt0 + t + (RING_NS - 1)) * BK;
-                const int pslot = (t + (RING_NS - 1)) & (RING_NS - 1);
-                static_for<0, NG>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
-                    if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
-                    if constexpr (g == 0) reads_kk(std::integral_constant<int, 1>{});   // second k step: 6 more reads in flight
-                    if constexpr (g == NG - 1) {
-                        fragr_wait<0>(faq[1][1]);
-                        if (t + 1 < nt) {
-                            const int ahead = nt - 2 - t;
-                            if (RING_NS > 3 && ahead >= 2)
-                                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                            else if (RING_NS > 2 && ahead >= 1)
-                                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                            else
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_s_barrier();
-                            const uint32_t so = (uint32_t)(((t + 1) & (RING_NS - 1)) * RING_STAGE);
-                            ab = s0 + offA + so;
-                            bb = s0 + offB + so;
-                            reads_kk(std::integral_constant<int, 0>{});   // next tile's first k step, under this group's MFMAs
-                        }
-                    }
-                    // outstanding reads YOUNGER than the fragment MFMA (kk, i, j) consumes: the rest of this k step's six plus, during
-                    // the first k step, the six of the second
-                    constexpr int later = (kk == 0) ? 6 : 0;
-                    if constexpr (i == 0) {
-                        fragr_wait<4 + later>(faq[kk][0]);        // B0 and A0 have arrived
-                        fragr_touch(fbq[kk][0]);
-                    } else if constexpr (g != NG - 1) {
-                        fragr_wait<0 + later>(faq[kk][1]);        // the whole k step has arrived
-                    }
-                    const bf16x8 va = fragr_value(faq[kk][i]);
-                    static_for<0, 4>([&](auto jc) {
-                        constexpr int j = decltype(jc)::value;
-                        if constexpr (i == 0 && j > 0) fragr_wait<(4 - j) + later>(fbq[kk][j]);   // B_j: (3 - j) B fragments + A1 younger
-                        if constexpr (i == 1) fragr_touch(fbq[kk][j]);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fbq[kk][j]), va, acc[i][j], 0, 0, 0);
-                    });
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                if (pf) conv_advance();
-            }
-        } else {
-            FragR<false> fa[2];
-            FragR<false> fb[2][4];
-            uint32_t ab = s0 + offA, bb = s0 + offB;
-            auto first_reads = [&]() {
-                static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, 0>(fb[0][decltype(j)::value], bb); });
-                fragr_issue<false, 0, 0>(fa[0], ab);
-            };
-            first_reads();
+        FragR<false> fa[2];
+        FragR<false> fb[2][4];
+        uint32_t ab = s0 + offA, bb = s0 + offB;
+        auto first_reads = [&]() {
+            static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, 0>(fb[0][decltype(j)::value], bb); });
+            fragr_issue<false, 0, 0>(fa[0], ab);
+        };
+        first_reads();
 
-            for (int t = 0; t < nt; ++t) {
-                // stage t+3 goes into the slot stage t-1 was read from: every wave finished those reads before the last barrier
-                const bool pf = t + (RING_NS - 1) < nt;
-                const int64_t kpf = (int64_t)(kt0 + t + (RING_NS - 1)) * BK;
-                const int pslot = (t + (RING_NS - 1)) & (RING_NS - 1);
-                static_for<0, NG>([&](auto gc) {
-                    constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
-                    if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
-                    if constexpr (g < NG - 1) {
-                        constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
-                        if constexpr (in == 0)
-                            static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, kn>(fb[kn][decltype(j)::value], bb); });
-                        fragr_issue<false, in, kn>(fa[(g + 1) & 1], ab);
-                        fragr_wait<1 + (in == 0 ? 4 : 0)>(fa[g & 1]);
-                    } else {
-                        fragr_wait<0>(fa[g & 1]);
-                        if (t + 1 < nt) {
-                            // stage t+1 must have landed (this wave's share; the barrier extends that to every wave's): the stages
-                            // issued after it -- at most two -- stay in flight across the barrier
-                            const int ahead = nt - 2 - t;
-                            if (RING_NS > 3 && ahead >= 2)
-                                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                            else if (RING_NS > 2 && ahead >= 1)
-                                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                            else
-                                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            __builtin_amdgcn_s_barrier();
-                            const uint32_t so = (uint32_t)(((t + 1) & (RING_NS - 1)) * RING_STAGE);
-                            ab = s0 + offA + so;
-                            bb = s0 + offB + so;
-                            first_reads();
-                        }
+        for (int t = 0; t < nt; ++t) {
+            // stage t+3 goes into the slot stage t-1 was read from: every wave finished those reads before the last barrier
+            const bool pf = t + (RING_NS - 1) < nt;
+            const int64_t kpf = (int64_t)(kt0 + t + (RING_NS - 1)) * BK;
+            const int pslot = (t + (RING_NS - 1)) & (RING_NS - 1);
+            static_for<0, NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
+                if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
+                if constexpr (g < NG - 1) {
+                    constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
+                    if constexpr (in == 0)
+                        static_for<0, 4>([&](auto j) { fragr_issue<false, decltype(j)::value, kn>(fb[kn][decltype(j)::value], bb); });
+                    fragr_issue<false, in, kn>(fa[(g + 1) & 1], ab);
+                    fragr_wait<1 + (in == 0 ? 4 : 0)>(fa[g & 1]);
+                } else {
+                    fragr_wait<0>(fa[g & 1]);
+                    if (t + 1 < nt) {
+                        // stage t+1 must have landed (this wave's share; the barrier extends that to every wave's): the stages
+                        // issued after it -- at most two -- stay in flight across the barrier
+                        const int ahead = nt - 2 - t;
+                        if (RING_NS > 3 && ahead >= 2)
+                            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                        else if (RING_NS > 2 && ahead >= 1)
+                            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        else
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        const uint32_t so = (uint32_t)(((t + 1) & (RING_NS - 1)) * RING_STAGE);
+                        ab = s0 + offA + so;
+                        bb = s0 + offB + so;
+                        first_reads();
                     }
-                    if constexpr (i == 0) static_for<0, 4>([&](auto j) { fragr_touch(fb[kk][decltype(j)::value]); });
-                    const bf16x8 va = fragr_value(fa[g & 1]);
+                }
+                if constexpr (i == 0) static_for<0, 4>([&](auto j) { fragr_touch(fb[kk][decltype(j)::value]); });
+                const bf16x8 va = fragr_value(fa[g & 1]);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                if (pf) conv_advance();
-            }
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (pf) conv_advance();
         }
     }
 
@@ -425,242 +358,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
     }
 }
 
-// ---- 16-wave form (experiment, tile code 272) -------------------------------------------------------------------------------------
-// What bounds the K step of the 8-wave kernel on a single resident block is the issue cost of its LDS-DMA requests (four 1-KiB requests
-// per wave and K tile, ~60-185 cycles each with the wave stalled: DESIGN.md §12) -- a second resident block hides it (the two-stage
-// form), but a grid of at most one block per CU has no second block.  Here the SAME 128 x 128 x 64 tile and four-stage ring are worked by
-// 16 waves (4 x 4 wave tiles of 32 x 32, four waves per SIMD): two requests and eight MFMAs per wave and K tile, so that three other
-// waves of the SIMD compute under a wave's request.  Direct epilogue (8-byte stores) / raw fp32 slabs for split-K.
-template <int AL, int RING_NS = 4>
-__global__ __launch_bounds__(1024, 4) void gemm_ring16_kernel(GemmParams P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 128, BN_OUT = 128, MI = 2, NJ = 2, NG = 2 * MI;
-    constexpr bool CONV = (AL == A_CONV || AL == A_CONVS), SHIFT = (AL == A_CONVS);
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave >> 2) * 32, wn = (wave & 3) * 32;
-
-    const int num_pid_m = (int)((P.M + BM - 1) / BM), num_pid_n = (int)((P.N + BN_OUT - 1) / BN_OUT);
-    const int nwg = num_pid_m * num_pid_n;
-    int wgid;
-    {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    int pid_m, pid_n;
-    {
-        const int GROUP_M = P.group_m > 0 ? P.group_m : 8;
-        const int in_group = GROUP_M * num_pid_n;
-        const int group_id = wgid / in_group;
-        const int first_m = group_id * GROUP_M;
-        const int gsz = min(num_pid_m - first_m, GROUP_M);
-        pid_m = first_m + (wgid % in_group) % gsz;
-        pid_n = (wgid % in_group) / gsz;
-    }
-    const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN_OUT;
-
-    int kt0 = 0, nt = (int)(P.K / BK);
-    if (P.splitk > 1) {
-        const int per = (nt + P.splitk - 1) / P.splitk;
-        kt0 = blockIdx.y * per;
-        nt = max(0, min(nt - kt0, per));
-    }
-
-    f32x4 acc[MI][NJ];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- per-lane DMA sources: the wave's ONE 8-row group of each operand tile (group index = wave)
-    const int dr = wave * 8 + (lane >> 3);                // row of the 128-row tile image
-    const int dc = ((lane & 7) ^ ((dr >> 1) & 7)) * 8;    // first element of the logical 16-byte chunk held at this lane's LDS position
-    const bf16* a_src = P.A;
-    int64_t pix_off = 0;
-    unsigned tapmask = 0, org = 0;
-    if constexpr (!CONV) {
-        int64_t row = m0 + dr;
-        row = row < P.M ? row : P.M - 1;
-        a_src = P.A + row * P.lda + dc;
-    } else {
-        const int64_t m = m0 + dr;
-        if (m < P.M) {
-            const ConvGeom& g = P.cv;
-            const int64_t hw = (int64_t)g.OH * g.OW;
-            const int64_t img = m / hw;
-            const int rem = (int)(m - img * hw);
-            const int oh = rem / g.OW, ow = rem - oh * g.OW;
-            const int ih0 = oh * g.stride - g.pad, iw0 = ow * g.stride - g.pad;
-            pix_off = img * (int64_t)g.H * g.W * g.C + (SHIFT ? (int64_t)0 : ((int64_t)ih0 * g.W + iw0) * g.C);
-            if constexpr (SHIFT) org = ((unsigned)(ih0 + 2) << 16) | (unsigned)(iw0 + 2);
-            for (int kh = 0; kh < g.KH; ++kh)
-                for (int kw = 0; kw < g.KW; ++kw) {
-                    int ih = ih0 + kh, iw = iw0 + kw;
-                    bool ok = ih >= 0 && iw >= 0;
-                    if (SHIFT) {
-                        if (g.even_only) ok = ok && ((ih & 1) == 0) && ((iw & 1) == 0);
-                        ih >>= 1;
-                        iw >>= 1;
-                    }
-                    if (ok && ih < g.H && iw < g.W) tapmask |= 1u << (kh * g.KW + kw);
-                }
-        }
-    }
-    const bf16* b_src;
-    {
-        int64_t n = n0 + dr;
-        n = n < P.N ? n : P.N - 1;
-        b_src = P.B + n * P.ldb + dc;
-    }
-    int ctap = 0, cci = 0;
-    if constexpr (CONV) {
-        ctap = (int)(((int64_t)kt0 * BK) / P.cv.C);
-        cci = (int)(((int64_t)kt0 * BK) % P.cv.C);
-    }
-    // q = 0: the wave's A group, q = 1: its B group, of the stage whose K tile starts at element k0, into ring slot `slot`
-    auto issue_one = [&](int64_t k0, int slot, int q) {
-        char* st = smem + slot * RING_STAGE;
-        if (q == 0) {
-            const bf16* src;
-            if constexpr (!CONV) {
-                src = a_src + k0;
-            } else {
-                const int kh = ctap / P.cv.KW, kw = ctap - kh * P.cv.KW;
-                const bool ok = (tapmask >> ctap) & 1u;
-                if constexpr (SHIFT) {
-                    const int ih = ((int)(org >> 16) - 2 + kh) >> 1, iw = ((int)(org & 0xffffu) - 2 + kw) >> 1;
-                    src = ok ? P.A + pix_off + (int64_t)((ih * P.cv.W + iw) * P.cv.C + cci + dc) : g_zero_page;
-                } else {
-                    src = ok ? P.A + pix_off + (int64_t)((kh * P.cv.W + kw) * P.cv.C + cci + dc) : g_zero_page;
-                }
-            }
-            GLDS16(src, st + wave * 1024);
-        } else {
-            GLDS16(b_src + k0, st + RING_TILE + wave * 1024);
-        }
-    };
-    auto conv_advance = [&]() {
-        if constexpr (CONV) {
-            cci += BK;
-            if (cci >= P.cv.C) {
-                cci -= P.cv.C;
-                ++ctap;
-            }
-        }
-    };
-
-    if (nt > 0) {
-        const int pre = nt < RING_NS - 1 ? nt : RING_NS - 1;
-        for (int s = 0; s < pre; ++s) {
-            issue_one((int64_t)(kt0 + s) * BK, s, 0);
-            issue_one((int64_t)(kt0 + s) * BK, s, 1);
-            conv_advance();
-        }
-        if (RING_NS > 3 && pre >= 3)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (RING_NS > 2 && pre == 2)
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-
-        const int lg = lane >> 4, lt = lane & 15;
-        const uint32_t s0 = lds_addr(smem);
-        const uint32_t offA = (uint32_t)kc_off(wm + lt, lg);
-        const uint32_t offB = (uint32_t)RING_TILE + (uint32_t)kc_off(wn + lt, lg);
-        FragR<false> fa[2];
-        FragR<false> fb[2][NJ];
-        uint32_t ab = s0 + offA, bb = s0 + offB;
-        auto first_reads = [&]() {
-            static_for<0, NJ>([&](auto j) { fragr_issue<false, decltype(j)::value, 0>(fb[0][decltype(j)::value], bb); });
-            fragr_issue<false, 0, 0>(fa[0], ab);
-        };
-        first_reads();
-
-        for (int t = 0; t < nt; ++t) {
-            const bool pf = t + (RING_NS - 1) < nt;
-            const int64_t kpf = (int64_t)(kt0 + t + (RING_NS - 1)) * BK;
-            const int pslot = (t + (RING_NS - 1)) & (RING_NS - 1);
-            static_for<0, NG>([&](auto gc) {
-                constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
-                if constexpr (g < 2) {
-                    if (pf) issue_one(kpf, pslot, g);
-                }
-                if constexpr (g < NG - 1) {
-                    constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
-                    if constexpr (in == 0)
-                        static_for<0, NJ>([&](auto j) { fragr_issue<false, decltype(j)::value, kn>(fb[kn][decltype(j)::value], bb); });
-                    fragr_issue<false, in, kn>(fa[(g + 1) & 1], ab);
-                    fragr_wait<1 + (in == 0 ? NJ : 0)>(fa[g & 1]);
-                } else {
-                    fragr_wait<0>(fa[g & 1]);
-                    if (t + 1 < nt) {
-                        const int ahead = nt - 2 - t;
-                        if (RING_NS > 3 && ahead >= 2)
-                            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                        else if (RING_NS > 2 && ahead >= 1)
-                            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-                        else
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                        const uint32_t so = (uint32_t)(((t + 1) & (RING_NS - 1)) * RING_STAGE);
-                        ab = s0 + offA + so;
-                        bb = s0 + offB + so;
-                        first_reads();
-                    }
-                }
-                if constexpr (i == 0) static_for<0, NJ>([&](auto j) { fragr_touch(fb[kk][decltype(j)::value]); });
-                const bf16x8 va = fragr_value(fa[g & 1]);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            if (pf) conv_advance();
-        }
-    }
-
-    // ---- epilogue: lane holds C[m][n .. n+3], m = m0 + wm + 16 i + (lane & 15), n = n0 + wn + 16 j + 4 (lane >> 4)
-    const bool vec_ok = ((P.N & 3) == 0) && ((P.ldc & 3) == 0) && (P.residual == nullptr || (P.ldr & 3) == 0);
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int64_t m = m0 + wm + i * 16 + (lane & 15);
-        if (m >= P.M) continue;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int64_t n = n0 + wn + j * 16 + (lane >> 4) * 4;
-            if (n >= P.N) continue;
-            if (P.splitk > 1) {   // raw fp32 partial slab of this K slice (N % 4 == 0 enforced by the host)
-                *reinterpret_cast<f32x4*>(P.ws + ((int64_t)blockIdx.y * P.M + m) * P.N + n) = acc[i][j];
-            } else {
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * P.alpha;
-                epilogue_store4(P, m, n, v, vec_ok);
-            }
-        }
-    }
-}
-
-template <int AL>
-int launch_ring16_t(const GemmParams& P, hipStream_t stream) {
-    const int64_t tiles = cdiv64(P.M, 128) * cdiv64(P.N, 128);
-    if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
-    static std::atomic<uint64_t> lds_ok{0};
-    dllm_ensure_dyn_lds(&gemm_ring16_kernel<AL, 4>, 4 * RING_STAGE, lds_ok);
-    const int sk = P.splitk > 1 ? P.splitk : 1;
-    hipLaunchKernelGGL((gemm_ring16_kernel<AL, 4>), dim3((unsigned)tiles, sk), dim3(1024), 4 * RING_STAGE, stream, P);
-    if (sk > 1) {
-        const int64_t work = P.M * (P.N >> 2);
-        const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, P);
-    }
-    return dllm_check_launch();
-}
-
 template <int AL, bool GLU>
-int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream, int deep = 0) {
+int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream) {
     const int64_t tiles = cdiv64(P.M, 128) * cdiv64(P.N, GLU ? 64 : 128);
     if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
     static std::atomic<uint64_t> lds_ok{0};
@@ -674,14 +373,7 @@ int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream, int de
     // Conv gathers keep winning beyond K = 2048 (profiles/r04_unet_conv_b16_ring_stages.log, batch 16: [65536, 320, 2880] 238 -> 175 us
     // against 193 for the 256 x 256 pipelined tile, [4096, 1280, 11520] 252 -> 221, [16384, 320, 2880] stride 2 72 -> 58): no K limit there.
     const bool ns2 = two_stage > 0 || (two_stage == 0 && (P.K <= 32 * BK || AL != A_K) && tiles * sk > (int64_t)dllm_num_cus());
-    if (deep) {
-        static std::atomic<uint64_t> ldsd_ok{0};
-        dllm_ensure_dyn_lds(&gemm_ring_kernel<AL, GLU, 4, true>, 4 * RING_STAGE, ldsd_ok);
-        if (ns2)
-            hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 2, true>), dim3((unsigned)tiles, sk), dim3(512), 2 * RING_STAGE, stream, P);
-        else
-            hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 4, true>), dim3((unsigned)tiles, sk), dim3(512), 4 * RING_STAGE, stream, P);
-    } else if (ns2)
+    if (ns2)
         hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 2>), dim3((unsigned)tiles, sk), dim3(512), 2 * RING_STAGE, stream, P);
     else
         hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 4>), dim3((unsigned)tiles, sk), dim3(512), 4 * RING_STAGE, stream, P);
@@ -698,22 +390,16 @@ int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream, int de
 // Preconditions (checked by the caller, gemm.hip: ring_ok): K % 64 == 0, K >= 64, B k-contiguous, conv: C % 64 == 0;
 // EPI_GEGLU: P.N = F with F % 64 == 0, no split-K, bf16 output, no residual / per-image bias.
 // two_stage: 0 automatic, 1 force the two-stage ring (two blocks per CU), -1 force the four-stage ring
-int dllm_launch_gemm_ring(const GemmParams& P, int layout_a, hipStream_t stream, int two_stage, int waves16) {
-    if (waves16 == 1 && P.epi != EPI_GEGLU && P.counters == nullptr) {
-        if (layout_a == A_K) return launch_ring16_t<A_K>(P, stream);
-        if (layout_a == A_CONV) return (P.cv.up_shift | P.cv.even_only) ? launch_ring16_t<A_CONVS>(P, stream) : launch_ring16_t<A_CONV>(P, stream);
-        return DLLM_ERR_SHAPE;
-    }
-    const int deep = waves16 == 2;   // (experiment selector: 1 = 16-wave form, 2 = deep fragment prefetch)
+int dllm_launch_gemm_ring(const GemmParams& P, int layout_a, hipStream_t stream, int two_stage) {
     if (P.epi == EPI_GEGLU) {
         if (layout_a != A_K || P.splitk > 1 || (P.N & 63) || P.out_f32 || P.residual != nullptr || P.rg_bias != nullptr || P.accumulate)
             return DLLM_ERR_SHAPE;
-        return launch_ring_t<A_K, true>(P, two_stage, stream, deep);
+        return launch_ring_t<A_K, true>(P, two_stage, stream);
     }
-    if (layout_a == A_K) return launch_ring_t<A_K, false>(P, two_stage, stream, deep);
+    if (layout_a == A_K) return launch_ring_t<A_K, false>(P, two_stage, stream);
     if (layout_a == A_CONV) {
-        if (P.cv.up_shift | P.cv.even_only) return launch_ring_t<A_CONVS, false>(P, two_stage, stream, deep);
-        return launch_ring_t<A_CONV, false>(P, two_stage, stream, deep);
+        if (P.cv.up_shift | P.cv.even_only) return launch_ring_t<A_CONVS, false>(P, two_stage, stream);
+        return launch_ring_t<A_CONV, false>(P, two_stage, stream);
     }
     return DLLM_ERR_SHAPE;
 }

@@ -439,7 +439,6 @@ __device__ __attribute__((aligned(16))) bf16 g_zero_page[8];
 
 // gemm_ring.hip: 128 x 128 tiles, 8 waves, 4-stage LDS-DMA ring (A k-contiguous or conv gather with C % 64 == 0, B k-contiguous,
 // K % 64 == 0); split-K through fp32 slabs + splitk_reduce_kernel.  layout_a: A_K or A_CONV (shift addressing chosen from P.cv).
-__attribute__((visibility("hidden"))) int dllm_launch_gemm_ring(const GemmParams& P, int layout_a, hipStream_t stream, int two_stage = 0,
-                                                                     int waves16 = 0);
+__attribute__((visibility("hidden"))) int dllm_launch_gemm_ring(const GemmParams& P, int layout_a, hipStream_t stream, int two_stage = 0);
 // gemm_mfma32.hip (experiment): the 256 x 256 pipelined kernel on v_mfma_f32_32x32x16_bf16; forward layout, full tiles, plain epilogue
 __attribute__((visibility("hidden"))) int dllm_launch_gemm_pipe32(const GemmParams& P, hipStream_t stream);
