@@ -40,6 +40,7 @@ struct Variant {
                          // without the bit a workspace passed with splitk <= 1 is ignored, as before round 3 -- no unchecked 128 MiB writes)
     int ring_stages = 0;  // tile codes 267 / 268: force the four- / two-stage ring (0: the launcher decides)
     int no_ring = 0;     // bit 25: never pick the ring-buffered kernel by itself (the round-3 selection: A/B knob of tools / bench)
+    int dma_mode = 0;      // bench builds: tile codes 271-276, placement of the ring kernel's LDS-DMA requests (experiment)
     int force_mfma32 = 0;  // tile code 266: the MFMA 32x32x16 experiment (gemm_mfma32.hip) wherever it is eligible (tools)
 };
 static inline int parse_variant(int variant, Variant& v) {
@@ -47,8 +48,12 @@ static inline int parse_variant(int variant, Variant& v) {
     v.group_m = (variant >> 16) & 0xff;
     bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262 || tile == 264 || tile == 266 || tile == 267 || tile == 268;
 #ifdef DLLM_BENCH_MODES
-    ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265;
-    v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : 0));
+    ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265 || (tile >= 269 && tile <= 278);
+    v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : ((tile >= 269 && tile <= 278) ? 4 : 0)));
+    // 271 / 272 / 273: 269 with the K tile's four LDS-DMA requests placed differently (all at the tile start / right behind the barrier /
+    // two and two); 274 / 275 / 276: the same for the two-stage ring
+    // 269 / 270: the ring kernel (four- / two-stage) with s_memtime stamps of block 0 / wave 0 around every K tile's wait and barrier,
+    // written to the workspace as uint64 (tools/ring_timeline.py): correct results, timing diagnostic only
 #endif
     if (!ok || (variant >> 28) != 0) return DLLM_ERR_SHAPE;
     if ((variant >> 27) & 1) v.ring_stages = -1;   // bit 27: the ring kernel always with four stages (round-4 A/B knob)
@@ -59,8 +64,9 @@ static inline int parse_variant(int variant, Variant& v) {
     v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 262 || tile == 263 || tile == 265);
     v.force_tile = tile >= 257 ? 256 : tile;
     v.force_n128 = tile == 262;
-    v.force_ring = tile == 264 || tile == 267 || tile == 268;   // 267: four-stage ring forced, 268: two-stage ring forced (tools)
-    if (tile == 267 || tile == 268) v.ring_stages = tile == 267 ? -1 : 1;
+    v.force_ring = tile == 264 || tile == 267 || tile == 268 || (tile >= 269 && tile <= 278);   // 267: four-stage ring forced, 268: two-stage ring forced (tools)
+    if (tile == 267 || tile == 268 || (tile >= 269 && tile <= 278)) v.ring_stages = (tile == 267 || tile == 269 || (tile >= 271 && tile <= 273) || tile >= 277) ? -1 : 1;
+    v.dma_mode = (tile >= 271 && tile <= 273) ? tile - 270 : ((tile >= 274 && tile <= 276) ? tile - 273 : ((tile == 277 || tile == 278) ? tile - 273 : 0));   // 277: no LDS-DMA in the loop, 278: no MFMAs (ablations, two-stage flag ignored: four-stage)
     v.force_mfma32 = tile == 266;
     if (v.force_ring) v.force_tile = 0;
     return DLLM_OK;
@@ -1004,7 +1010,7 @@ static inline double tile_cost_us(int64_t M, int64_t N, int64_t K, int TM, int T
 template <int AL, int BL>
 static inline bool ring_ok(const GemmParams& P) {
     if constexpr (BL != B_K || (AL != A_K && AL != A_CONV)) return false;
-    if (P.dbg_noload != 0) return false;
+    if (P.dbg_noload != 0 && P.dbg_noload != 4) return false;
     if ((P.K % BK) != 0 || P.K < BK) return false;
     if (AL == A_CONV && (P.cv.C % BK) != 0) return false;
     return true;
@@ -1015,7 +1021,12 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     if (P.M <= 0 || P.N <= 0) return DLLM_OK;
     bool ring = ring_ok<AL, BL>(P);
     if (P.epi == EPI_GEGLU) return ring ? dllm_launch_gemm_ring(P, AL, stream, V.ring_stages) : DLLM_ERR_SHAPE;   // only the ring kernel pairs the columns
-    if (V.force_ring && ring) return dllm_launch_gemm_ring(P, AL, stream, V.ring_stages);
+    if (V.force_ring && ring) {
+        if (V.dma_mode == 0) return dllm_launch_gemm_ring(P, AL, stream, V.ring_stages);
+        GemmParams Q = P;
+        Q.sk_w = V.dma_mode;
+        return dllm_launch_gemm_ring(Q, AL, stream, V.ring_stages);
+    }
     if constexpr (AL == A_K && BL == B_K) {
         if (V.force_mfma32 && (P.M % 256) == 0 && (P.N % 256) == 0 && (P.K % BK) == 0 && P.K >= BK && !P.out_f32 && P.bias == nullptr &&
             P.residual == nullptr && P.rg_bias == nullptr && P.epi == 0 && !P.accumulate && P.splitk <= 1 && (P.ldc & 7) == 0 &&

@@ -103,6 +103,23 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
     }
     const int64_t m0 = (int64_t)pid_m * BM, n0 = (int64_t)pid_n * BN_OUT;
 
+#ifdef DLLM_BENCH_MODES
+    // timing diagnostic (tile codes 269 / 270, bench library only): wave 0 of block 0 stamps s_memtime into 8 KiB of LDS behind the ring
+    // -- at points where its LDS queue is empty anyway -- and copies the stamps to the workspace (uint64) at the end
+    const bool ts_on = P.dbg_noload == 4 && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && P.ws != nullptr;
+    uint64_t* ts_lds = reinterpret_cast<uint64_t*>(smem + RING_NS * RING_STAGE);
+#define RING_TS(slot)                                                 \
+    if (ts_on) {                                                      \
+        const uint64_t tt_ = __builtin_amdgcn_s_memtime();            \
+        if (lane == 0 && (slot) < 1000) ts_lds[(slot)] = tt_;         \
+    }
+#else
+#define RING_TS(slot)
+#endif
+    RING_TS(0)
+#ifdef DLLM_BENCH_MODES
+    const int dma_mode = (P.dbg_noload == 4) ? P.sk_w : 0;   // placement of a K tile's four LDS-DMA requests (experiment)
+#endif
     // this block's K tiles [kt0, kt0 + nt)
     int kt0 = 0, nt = (int)(P.K / BK);
     if (P.splitk > 1) {
@@ -199,6 +216,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        RING_TS(1)
 
         const int lg = lane >> 4, lt = lane & 15;
         const uint32_t s0 = lds_addr(smem);
@@ -220,7 +238,25 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
             const int pslot = (t + (RING_NS - 1)) & (RING_NS - 1);
             static_for<0, NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
+#ifdef DLLM_BENCH_MODES
+                if (dma_mode == 0 || dma_mode == 5) {
+                    if (pf) issue_one(kpf, pslot, g);
+                } else if (dma_mode == 1 || (dma_mode == 2 && t == 0)) {   // all four at the start of the tile
+                    if constexpr (g == 0) {
+                        if (pf) {
+                            issue_one(kpf, pslot, 0); issue_one(kpf, pslot, 1); issue_one(kpf, pslot, 2); issue_one(kpf, pslot, 3);
+                        }
+                    }
+                } else if (dma_mode == 3) {   // two and two
+                    if constexpr (g == 0 || g == 2) {
+                        if (pf) {
+                            issue_one(kpf, pslot, g); issue_one(kpf, pslot, g + 1);
+                        }
+                    }
+                }
+#else
                 if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
+#endif
                 if constexpr (g < NG - 1) {
                     constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
                     if constexpr (in == 0)
@@ -233,30 +269,57 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
                         // stage t+1 must have landed (this wave's share; the barrier extends that to every wave's): the stages
                         // issued after it -- at most two -- stay in flight across the barrier
                         const int ahead = nt - 2 - t;
+                        RING_TS(2 + 3 * t)
                         if (RING_NS > 3 && ahead >= 2)
                             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                         else if (RING_NS > 2 && ahead >= 1)
                             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                         else
                             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        RING_TS(3 + 3 * t)
                         __builtin_amdgcn_s_barrier();
+                        RING_TS(4 + 3 * t)
                         const uint32_t so = (uint32_t)(((t + 1) & (RING_NS - 1)) * RING_STAGE);
                         ab = s0 + offA + so;
                         bb = s0 + offB + so;
+#ifdef DLLM_BENCH_MODES
+                        if (dma_mode == 2 && t + RING_NS < nt) {   // the tile after next's refill, right behind the barrier (LDS queue empty)
+                            if (pf) conv_advance();                // (this tile's own stage was issued earlier: account for it first)
+                            const int64_t k2 = (int64_t)(kt0 + t + RING_NS) * BK;
+                            const int s2 = (t + RING_NS) & (RING_NS - 1);
+                            issue_one(k2, s2, 0); issue_one(k2, s2, 1); issue_one(k2, s2, 2); issue_one(k2, s2, 3);
+                        }
+#endif
                         first_reads();
                     }
                 }
                 if constexpr (i == 0) static_for<0, 4>([&](auto j) { fragr_touch(fb[kk][decltype(j)::value]); });
                 const bf16x8 va = fragr_value(fa[g & 1]);
+#ifdef DLLM_BENCH_MODES
+                if (dma_mode == 5) {   // ablation: no matrix instructions (wrong results)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 4; ++j) {
+                        bf16x8 vb = fragr_value(fb[kk][j]);
+                        asm volatile("" ::"v"(vb), "v"(va));
+                    }
+                } else
+#endif
+                {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
+#ifdef DLLM_BENCH_MODES
+            if (pf && !(dma_mode == 2 && t + RING_NS < nt)) conv_advance();
+#else
             if (pf) conv_advance();
+#endif
         }
     }
 
+    RING_TS(2 + 3 * (nt > 0 ? nt - 1 : 0))
     if constexpr (GLU) {
         // lane holds, for rows m = m0 + wm + 16 i + (lane & 15): hidden acc[i][0..1] and gate acc[i][2..3] of the output columns
         // n = n0 + 32 (wave & 1) + 16 j + 4 (lane >> 4) + 0..3, j = 0, 1
@@ -355,6 +418,15 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
             for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
             st_bf16x8(C + m * P.ldc + n, o);
         }
+#ifdef DLLM_BENCH_MODES
+        RING_TS(3 + 3 * (nt > 0 ? nt - 1 : 0))
+        if (ts_on && lane == 0) {   // stamps: [0] start, [1] prologue done, per K tile t {2+3t before the wait, 3+3t after it, 4+3t after the barrier}
+            uint64_t* out = reinterpret_cast<uint64_t*>(P.ws);
+            const int n = 4 + 3 * (nt > 0 ? nt - 1 : 0);
+            for (int i = 0; i < n && i < 1000; ++i) out[i] = ts_lds[i];
+            out[1000] = (uint64_t)nt;
+        }
+#endif
     }
 }
 
@@ -373,6 +445,17 @@ int launch_ring_t(const GemmParams& P, int two_stage, hipStream_t stream) {
     // Conv gathers keep winning beyond K = 2048 (profiles/r04_unet_conv_b16_ring_stages.log, batch 16: [65536, 320, 2880] 238 -> 175 us
     // against 193 for the 256 x 256 pipelined tile, [4096, 1280, 11520] 252 -> 221, [16384, 320, 2880] stride 2 72 -> 58): no K limit there.
     const bool ns2 = two_stage > 0 || (two_stage == 0 && (P.K <= 32 * BK || AL != A_K) && tiles * sk > (int64_t)dllm_num_cus());
+#ifdef DLLM_BENCH_MODES
+    if (P.dbg_noload == 4) {   // timing diagnostic: 8 KiB of stamp space behind the ring
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<AL, GLU, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * RING_STAGE + 8192);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_ring_kernel<AL, GLU, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * RING_STAGE + 8192);
+        if (ns2)
+            hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 2>), dim3((unsigned)tiles, sk), dim3(512), 2 * RING_STAGE + 8192, stream, P);
+        else
+            hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 4>), dim3((unsigned)tiles, sk), dim3(512), 4 * RING_STAGE + 8192, stream, P);
+        return dllm_check_launch();
+    }
+#endif
     if (ns2)
         hipLaunchKernelGGL((gemm_ring_kernel<AL, GLU, 2>), dim3((unsigned)tiles, sk), dim3(512), 2 * RING_STAGE, stream, P);
     else

@@ -109,7 +109,9 @@ int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int la
  * splitk = 1 would have been written out of bounds); bit 27 = the ring-buffered kernel never takes its two-stage form (A/B knob).
  * Tests pass 128 / 256 / 257 / 259 / 262 / 264 to cover
  * every kernel family.  Anything else returns DLLM_ERR_SHAPE.  (A build with -DDLLM_BENCH_MODES additionally accepts the
- * wrong-result diagnostic modes 258 / 260 / 263 / 265 used by tools/; the shipped library does not contain them.) */
+ * wrong-result diagnostic modes 258 / 260 / 263 / 265 and the ring kernel's timing diagnostics 269-278 (s_memtime stamps of one block written to
+ * the workspace, request-placement variants, no-DMA / no-MFMA ablations: tools/ring_timeline.py) used by tools/; the shipped library does not
+ * contain them.) */
 int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bias, const void* residual, int64_t M, int64_t N,
                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
                           int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int* counters, int variant,
