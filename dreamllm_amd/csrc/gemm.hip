@@ -40,7 +40,7 @@ struct Variant {
                          // without the bit a workspace passed with splitk <= 1 is ignored, as before round 3 -- no unchecked 128 MiB writes)
     int ring_stages = 0;  // tile codes 267 / 268: force the four- / two-stage ring (0: the launcher decides)
     int no_ring = 0;     // bit 25: never pick the ring-buffered kernel by itself (the round-3 selection: A/B knob of tools / bench)
-    int dma_mode = 0;      // bench builds: tile codes 271-276, placement of the ring kernel's LDS-DMA requests (experiment)
+    int dma_mode = -1;     // bench builds: tile codes 271-276, placement of the ring kernel's LDS-DMA requests (experiment)
     int force_mfma32 = 0;  // tile code 266: the MFMA 32x32x16 experiment (gemm_mfma32.hip) wherever it is eligible (tools)
 };
 static inline int parse_variant(int variant, Variant& v) {
@@ -48,8 +48,8 @@ static inline int parse_variant(int variant, Variant& v) {
     v.group_m = (variant >> 16) & 0xff;
     bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262 || tile == 264 || tile == 266 || tile == 267 || tile == 268;
 #ifdef DLLM_BENCH_MODES
-    ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265 || (tile >= 269 && tile <= 278);
-    v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : ((tile >= 269 && tile <= 278) ? 4 : 0)));
+    ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265 || (tile >= 269 && tile <= 279);
+    v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : ((tile >= 269 && tile <= 279) ? 4 : 0)));
     // 271 / 272 / 273: 269 with the K tile's four LDS-DMA requests placed differently (all at the tile start / right behind the barrier /
     // two and two); 274 / 275 / 276: the same for the two-stage ring
     // 269 / 270: the ring kernel (four- / two-stage) with s_memtime stamps of block 0 / wave 0 around every K tile's wait and barrier,
@@ -64,9 +64,9 @@ static inline int parse_variant(int variant, Variant& v) {
     v.glds_pipe = (tile == 0 || tile == 259 || tile == 260 || tile == 262 || tile == 263 || tile == 265);
     v.force_tile = tile >= 257 ? 256 : tile;
     v.force_n128 = tile == 262;
-    v.force_ring = tile == 264 || tile == 267 || tile == 268 || (tile >= 269 && tile <= 278);   // 267: four-stage ring forced, 268: two-stage ring forced (tools)
-    if (tile == 267 || tile == 268 || (tile >= 269 && tile <= 278)) v.ring_stages = (tile == 267 || tile == 269 || (tile >= 271 && tile <= 273) || tile >= 277) ? -1 : 1;
-    v.dma_mode = (tile >= 271 && tile <= 273) ? tile - 270 : ((tile >= 274 && tile <= 276) ? tile - 273 : ((tile == 277 || tile == 278) ? tile - 273 : 0));   // 277: no LDS-DMA in the loop, 278: no MFMAs (ablations, two-stage flag ignored: four-stage)
+    v.force_ring = tile == 264 || tile == 267 || tile == 268 || (tile >= 269 && tile <= 279);   // 267: four-stage ring forced, 268: two-stage ring forced (tools)
+    if (tile == 267 || tile == 268 || (tile >= 269 && tile <= 279)) v.ring_stages = (tile == 267 || tile == 269 || (tile >= 271 && tile <= 273) || tile >= 277) ? -1 : 1;
+    v.dma_mode = (tile >= 271 && tile <= 273) ? tile - 270 : ((tile >= 274 && tile <= 276) ? tile - 273 : ((tile == 277 || tile == 278) ? tile - 273 : (tile == 279 ? 0 : -1)));   // -1: the kernel's default; 279: two-stage with one request per MFMA group   // 277: no LDS-DMA in the loop, 278: no MFMAs (ablations, two-stage flag ignored: four-stage)
     v.force_mfma32 = tile == 266;
     if (v.force_ring) v.force_tile = 0;
     return DLLM_OK;
@@ -1022,9 +1022,9 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
     bool ring = ring_ok<AL, BL>(P);
     if (P.epi == EPI_GEGLU) return ring ? dllm_launch_gemm_ring(P, AL, stream, V.ring_stages) : DLLM_ERR_SHAPE;   // only the ring kernel pairs the columns
     if (V.force_ring && ring) {
-        if (V.dma_mode == 0) return dllm_launch_gemm_ring(P, AL, stream, V.ring_stages);
+        if (V.dma_mode < 0) return dllm_launch_gemm_ring(P, AL, stream, V.ring_stages);
         GemmParams Q = P;
-        Q.sk_w = V.dma_mode;
+        Q.sk_w = V.dma_mode + 1;   // (0 = the kernel's own default placement)
         return dllm_launch_gemm_ring(Q, AL, stream, V.ring_stages);
     }
     if constexpr (AL == A_K && BL == B_K) {

@@ -117,8 +117,16 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
 #define RING_TS(slot)
 #endif
     RING_TS(0)
+    // Placement of a K tile's four LDS-DMA requests.  0 (shipped): one in front of each MFMA group.  The bench library can override it
+    // per call (tile codes 271-279): 1 all four at the tile start, 2 all four right behind the tile barrier (for the stage RING_NS tiles
+    // ahead), 3 two and two; 4 / 5 are the no-DMA / no-MFMA ablations.  Measured (profiles/r04_ring_timeline.log, r04_denoise_ring_early_
+    // requests_ab.log): +-3 % on the four-stage ring; on the two-stage ring placement 2 cuts the stamped block's vmcnt wait from 540-680
+    // to 140-150 clocks per tile -- and LOSES 6 % on the denoising loop at B_img = 8 (41.5 -> 39.1 steps/s): the burst of requests of
+    // one block lands on its co-resident partner.  Shipped: 0 everywhere.
 #ifdef DLLM_BENCH_MODES
-    const int dma_mode = (P.dbg_noload == 4) ? P.sk_w : 0;   // placement of a K tile's four LDS-DMA requests (experiment)
+    const int dma_mode = (P.dbg_noload == 4 && P.sk_w > 0) ? P.sk_w - 1 : 0;
+#else
+    constexpr int dma_mode = 0;
 #endif
     // this block's K tiles [kt0, kt0 + nt)
     int kt0 = 0, nt = (int)(P.K / BK);
@@ -238,9 +246,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
             const int pslot = (t + (RING_NS - 1)) & (RING_NS - 1);
             static_for<0, NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
-#ifdef DLLM_BENCH_MODES
                 if (dma_mode == 0 || dma_mode == 5) {
-                    if (pf) issue_one(kpf, pslot, g);
+                    if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
                 } else if (dma_mode == 1 || (dma_mode == 2 && t == 0)) {   // all four at the start of the tile
                     if constexpr (g == 0) {
                         if (pf) {
@@ -254,9 +261,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
                         }
                     }
                 }
-#else
-                if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
-#endif
                 if constexpr (g < NG - 1) {
                     constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
                     if constexpr (in == 0)
@@ -282,14 +286,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
                         const uint32_t so = (uint32_t)(((t + 1) & (RING_NS - 1)) * RING_STAGE);
                         ab = s0 + offA + so;
                         bb = s0 + offB + so;
-#ifdef DLLM_BENCH_MODES
-                        if (dma_mode == 2 && t + RING_NS < nt) {   // the tile after next's refill, right behind the barrier (LDS queue empty)
-                            if (pf) conv_advance();                // (this tile's own stage was issued earlier: account for it first)
+                        if (dma_mode == 2 && t + RING_NS < nt) {   // stage t + NS into the slot tile t was just read from (every wave is
+                            if (pf) conv_advance();                // past the barrier); the stage issued earlier is accounted for first
                             const int64_t k2 = (int64_t)(kt0 + t + RING_NS) * BK;
                             const int s2 = (t + RING_NS) & (RING_NS - 1);
                             issue_one(k2, s2, 0); issue_one(k2, s2, 1); issue_one(k2, s2, 2); issue_one(k2, s2, 3);
                         }
-#endif
                         first_reads();
                     }
                 }
@@ -311,11 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
-#ifdef DLLM_BENCH_MODES
             if (pf && !(dma_mode == 2 && t + RING_NS < nt)) conv_advance();
-#else
-            if (pf) conv_advance();
-#endif
         }
     }
 
