@@ -1134,7 +1134,7 @@ int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v,
     P.causal = causal;
     // automatic: the 256-row kernels where the row axis they tile is long enough to fill their blocks (UNet cross-attention has
     // Sq = 4096 queries over Sk = 64 dream tokens: wide dQ, 4-wave dK/dV)
-    const bool wq = force == 2 || (force == 0 && Sq >= 512), wk = force == 2 || (force == 0 && Sk >= 512);
+    const bool wq = force >= 2 || (force == 0 && Sq >= 512), wk = force >= 2 || (force == 0 && Sk >= 512);  // 3 = forward-only choice
     if (D == 128) return causal ? launch_bwd<128, true>(P, s, wq, wk) : launch_bwd<128, false>(P, s, wq, wk);
     return causal ? launch_bwd<64, true>(P, s, wq, wk) : launch_bwd<64, false>(P, s, wq, wk);
 }

@@ -640,6 +640,8 @@ int launch_fwd(const AttnParams& P, hipStream_t stream) {
 
 }  // namespace
 
+__attribute__((visibility("hidden"))) int dllm_launch_attn_fwd_pp(const AttnParams& P, int D, int causal, hipStream_t stream);  // attn_fwd_pp.hip
+
 extern "C" {
 
 // q,o: [B,Sq,H,D] views (element strides sb, ss, sh; d contiguous); k,v: [B,Sk,Hkv,D] views sharing one stride set.
@@ -671,7 +673,10 @@ int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     const int force = causal >> 1;
     causal &= 1;
     P.causal = causal;
-    const bool wide = force == 2 || (force == 0 && Sq >= 512);
+    // force 3 = the ping-pong kernel of attn_fwd_pp.hip (32-bit per-lane source byte offsets: one (batch, head) key axis must span less than 2 GiB)
+    const bool pp_ok = (int64_t)Sk * k_ss < (1ll << 30);
+    if (force == 3 && pp_ok) return dllm_launch_attn_fwd_pp(P, D, causal, s);
+    const bool wide = force == 2 || force == 3 || (force == 0 && Sq >= 512);
     if (wide) {
         if (D == 128) return causal ? launch_fwd8<128, true>(P, s) : launch_fwd8<128, false>(P, s);
         return causal ? launch_fwd8<64, true>(P, s) : launch_fwd8<64, false>(P, s);
@@ -681,6 +686,18 @@ int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
 }
 
 #ifdef DLLM_BENCH_MODES
+// benchmark-only: the ping-pong forward (causal, head_dim 128, [B,S,H,D] contiguous) with s_memtime stamps of work-group 0 written
+// to `stamps` (2 x 512 uint64: wave 0, wave 4; two stamps around every barrier of the first pass)
+int dllm_attn_fwd_pp_timeline(const void* q, const void* k, const void* v, void* o, float* lse, void* stamps, int B, int H, int Sq,
+                              int abl, void* stream) {
+    AttnParams P{};
+    const int D = 128;
+    P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.o = (bf16*)o; P.lse = lse; P.delta = (float*)stamps;
+    P.B = B; P.H = H; P.Hkv = H; P.Sq = Sq; P.Sk = Sq;
+    P.q_sb = P.k_sb = P.o_sb = (int64_t)Sq * H * D; P.q_ss = P.k_ss = P.o_ss = (int64_t)H * D; P.q_sh = P.k_sh = P.o_sh = D;
+    P.scale = 0.08838834764f; P.causal = 1;
+    return dllm_launch_attn_fwd_pp(P, D, 1 | (abl << 8), (hipStream_t)stream);
+}
 // benchmark-only: the causal head_dim-128 forward with one cost removed (see ABL above); results are wrong by design
 int dllm_attn_fwd_ablate(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Sq, int D, int abl,
                          void* stream) {

@@ -358,9 +358,10 @@ def attn_ref(q, k, v, causal, seqlen=None):
     return o.transpose(1, 2), lse
 
 
-@pytest.fixture(params=[1, 2], ids=["4wave", "8wave"])
+@pytest.fixture(params=[1, 2, 3], ids=["4wave", "8wave", "pingpong"])
 def attn_variant(request):
-    """every attention test runs on both kernel families (4-wave blocks / 8-wave pipelined 256-row blocks)"""
+    """every attention test runs on all kernel families (4-wave blocks / 8-wave pipelined 256-row blocks / the round-5 ping-pong
+    forward, which pairs with the 8-wave backward)"""
     from dreamllm_amd import ops
     ops.ATTN_VARIANT = request.param
     yield request.param

@@ -33,7 +33,7 @@ for name, B, Sq, Sk, H, D, causal in shapes:
     flops = 4 * Sq * Sk * D * H * B / (2 if causal else 1)
     res = {}
     for rnd in range(2):
-        for var in (1, 2):
+        for var in (1, 2, 3):
             ops.ATTN_VARIANT = var
             res.setdefault(var, []).append(timed(lambda: ops.attn_fwd(q, k, v, causal)))
     ops.ATTN_VARIANT = 0
