@@ -670,13 +670,15 @@ int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
     hipStream_t s = (hipStream_t)stream;
     // kernel choice: bit 1 of `causal` forces the 4-wave kernel, bit 2 the 8-wave pipelined one (tests cover both on every
     // shape); automatic = 8-wave for long query sequences, 4-wave (128-query blocks fill the chip better) for short ones
-    const int force = causal >> 1;
+    const int force = (causal >> 1) & 3;
     causal &= 1;
     P.causal = causal;
-    // force 3 = the ping-pong kernel of attn_fwd_pp.hip (32-bit per-lane source byte offsets: one (batch, head) key axis must span less than 2 GiB)
-    const bool pp_ok = (int64_t)Sk * k_ss < (1ll << 30);
-    if (force == 3 && pp_ok) return dllm_launch_attn_fwd_pp(P, D, causal, s);
+    // force 3 = the ping-pong kernel of attn_fwd_pp.hip (32-bit per-lane source byte offsets: one (batch, head) key axis must span less than 1 GiB)
+    const bool pp_ok = (int64_t)Sk * k_ss < (1ll << 29);
     const bool wide = force == 2 || force == 3 || (force == 0 && Sq >= 512);
+    // automatic choice on long query axes = the ping-pong kernel (round 5: 830 vs 761 TF at B16 S2048 H32 D128 causal, 880 vs 754 TF at
+    // the UNet's S = 4096 d64 shape, profiles/r05_attn_bench.log); force 2 keeps the 8-wave pipelined kernel reachable for tests / tools
+    if ((force == 3 || (force == 0 && wide)) && pp_ok) return dllm_launch_attn_fwd_pp(P, D, causal, s);
     if (wide) {
         if (D == 128) return causal ? launch_fwd8<128, true>(P, s) : launch_fwd8<128, false>(P, s);
         return causal ? launch_fwd8<64, true>(P, s) : launch_fwd8<64, false>(P, s);

@@ -26,6 +26,7 @@
 namespace {
 
 constexpr float kNegBigPP = -1.0e30f;
+constexpr unsigned kTlBlock = 1024;  // the work-group the timeline diagnostic stamps: mid-grid (warm caches, steady state), XCD 0
 
 __device__ __forceinline__ float pp_max3(float a, float b, float c) {
     float r;
@@ -97,8 +98,9 @@ __device__ __forceinline__ void pp_barrier() {
 
 // TL (bench library only): lane 0 of waves 0 and 4 of work-group 0 stamps s_memtime at both ends of every segment of the first pass
 // into LDS behind the rings (asm ds_write: invisible to hipcc's wait insertion); the stamps go to P.delta after the pass.
-// ABL (bench library only, wrong results by design): 1 no in-loop DMA requests, 2 no fillers beside the P V MFMAs, 4 no row max /
-// rescale / exponentials in L_V, 8 no LDS fragment reads (registers keep stale values).
+// ABL (bench library only): ablations with wrong results by design -- 1 no in-loop DMA requests, 2 no VALU fillers beside the P V MFMAs,
+// 4 no softmax head -- and priority experiments with correct results -- 16 group B at s_setprio 1 throughout, 32 every wave at priority
+// 1 inside its MFMA clusters, 64 group B at priority 1 in X only.
 template <int D, bool CAUSAL, int PF, bool TL = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
     constexpr int NW = 8, QW = 32, BQ = NW * QW, BKV = 64;
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
     [[maybe_unused]] uint32_t tl_addr = 0;
     [[maybe_unused]] bool tl_on = false;
     if constexpr (TL) {
-        tl_on = blockIdx.x == 0 && (wave == 0 || wave == 4);
+        tl_on = blockIdx.x == kTlBlock && (wave == 0 || wave == 4);
         tl_addr = lds_addr32(smem) + 2 * PF * TILE + (wave == 4 ? 4096 : 0);
     }
 #define PP_STAMP()                                                                                         \
@@ -133,6 +135,15 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
             }                                                                                              \
         }                                                                                                  \
     } while (0)
+
+#define PP_PHASE(idx)                                                                                                   \
+    do {                                                                                                                \
+        if constexpr (TL) {                                                                                             \
+            if (blockIdx.x == kTlBlock && (wave == 0 || wave == 4) && lane == 0)                                            \
+                reinterpret_cast<uint64_t*>(P.delta)[1024 + (wave == 4 ? 64 : 0) + (idx)] = __builtin_amdgcn_s_memtime(); \
+        }                                                                                                               \
+    } while (0)
+    PP_PHASE(0);
 
     const int nqb = (P.Sq + BQ - 1) / BQ;
     const int nitems = CAUSAL ? (nqb + 1) / 2 : nqb;  // causal: the pair (heaviest, lightest) remaining row block per work-group
@@ -164,16 +175,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
         koff[i] = (uint32_t)(r * (int)P.k_ss + kc * 8) * 2u;
         voff[i] = (uint32_t)(r * (int)P.k_ss + vc * 8) * 2u;
     }
-    // one 1-KiB DMA group (NDMA per wave and tile) of tile rows [row0, row0 + BKV) into ring slot `slot`: uniform 64-bit tile base +
-    // the lane's 32-bit byte offset (dllm_attn_fwd only sends shapes here whose key axis spans less than 2 GiB)
-    auto dma_one = [&](const bf16* base, const uint32_t (&offb)[NDMA], char* ring, int row0, int slot, int i) {
+    // One 1-KiB DMA group (NDMA per wave and tile) of key tile `t` into ring slot `slot`: uniform 64-bit tile base + the lane's 32-bit
+    // byte offset (dllm_attn_fwd only sends shapes here whose key axis spans less than 1 GiB).  Tiles past the end of the pass re-fetch
+    // the last one (into a slot nobody reads any more): the request stream -- and with it every counted wait -- stays uniform.
+    const int kss2 = (int)P.k_ss * 2;
+    auto dma_one = [&](const bf16* base, const uint32_t (&offb)[NDMA], char* ring, int t, int nblk_, int slot, int i) {
         char* dst = ring + slot * TILE + (wave * NDMA + i) * 1024;
-        const char* tb = reinterpret_cast<const char*>(base + (int64_t)row0 * P.k_ss);
+        const int row0 = min(t, nblk_ - 1) * BKV;
+        const char* tb = reinterpret_cast<const char*>(base) + (uint32_t)(row0 * kss2);
         uint32_t o = offb[i];
         if (row0 + BKV > sk_len) {  // ragged last tile (rare): rows past the end re-read the last valid row (finite data; masked later)
             asm volatile("" ::: "memory");  // keeps this path a branch (not if-converted into the common one)
             const int r = (wave * NDMA + i) * RPG + drow;
-            if (row0 + r > sk_len - 1) o = o - (uint32_t)(r * (int)P.k_ss * 2) + (uint32_t)((sk_len - 1 - row0) * (int)P.k_ss * 2);
+            if (row0 + r > sk_len - 1) o = o - (uint32_t)(r * kss2) + (uint32_t)((sk_len - 1 - row0) * kss2);
         }
         GLDS16_(tb + o, dst);
     };
@@ -221,26 +235,32 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
         int kv_end = sk_len;
         if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
         const int nblk = kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0;
+        PP_PHASE(1 + 4 * pass);
 
-        // ---- DMA schedule (per wave, in this order): K0 V0 K1 .. K(PF-1) in the prologue, then V(j + PF - 1) beside the MFMAs of C_QK(j)
-        // and K(j + PF) beside those of C_PV(j) -- an LDS-DMA request costs the issuing wave ~60 cycles among MFMAs but 100-185 in a
-        // segment that also issues LDS reads (MI355X_MICROARCH.md), and the slots are free by then: V(j - 1) was read in L_V(j - 1) by
-        // both groups before either reaches C_QK(j), K(j) in L_K(j) before either reaches C_PV(j).  The requests retire in order, so at
-        // the end of L_V(j) "K(j + 1) landed" and at the end of L_K(j + 1) "V(j + 1) landed" both mean: at most 2 PF - 3 younger shares
-        // outstanding -- provided the youngest of them was issued at all (the last tiles of a pass drain with vmcnt(0)).
-        constexpr int YOUNGER = (2 * PF - 3) * NDMA;
-        {
-            const int npre = min(PF, nblk);
-            for (int i = 0; i < npre; ++i) {
+        // ---- Structure of a pass (round-5 "v5").  Per key tile j a wave runs two segments, separated by work-group barriers:
+        //   X(j): C_QK(j) = the 2 DSN MFMAs of S^T = K Q^T out of the K fragments that are already in registers; beside them (fillers)
+        //         the transpose reads of V(j) -- into the registers the K fragments vacate -- and the DMA requests of tile j + PF - 1.
+        //   Y(j): the serial head of the online softmax (row max, rescale decision, exponents, P of the first 16 keys), then C_PV(j) =
+        //         the NF MFMAs of O^T += V^T P^T; beside them the exponentials / packs / row sums of the other 48 keys, the reads of
+        //         K(j + 1) into the registers the V fragments vacate.
+        //   The older wave of a SIMD wins every arbitration (matrix pipe and VALU: tools/mfma_filler_probe.hip -- two waves in MFMA
+        //   clusters at once run one after the other), so the cut is placed where the partner's work is complementary: a wave's
+        //   softmax head (no MFMA) opens the segment whose partner segment is the pure cluster X.
+        // Group B (waves 4-7) runs ONE segment behind group A, so one wave of a SIMD is in X while its partner is in Y.  There is no
+        // load-only segment: every LDS read has a whole cluster between its request and its wait.
+        // DMA stream per wave: K0 V0 .. K(PF-2) V(PF-2) (prologue), then V(j + PF - 1) and K(j + PF - 1) beside the MFMAs of X(j) (the
+        // shorter segment); requests retire in order, so the waits at the segment ends are counted (below).  Slots: both reuse slot
+        // (j - 1) % PF -- V(j - 1) was read in X(j - 1) and K(j - 1) in Y(j - 2) by both groups before either reaches X(j).
+        constexpr int YOUNGER_X = (1 + 2 * (PF - 2)) * NDMA;  // end of X(j): V(j + 1) landed <=> at most K(j + 1) .. K(j + PF - 1) outstanding
+        constexpr int YOUNGER_Y = 2 * (PF - 3) * NDMA;        // end of Y(j): K(j + 2) landed <=> at most V(j + 3) .. K(j + PF - 1) outstanding
+        static_assert(PF >= 3, "K(j + 2) is requested in X(j + 3 - PF)");
+        for (int i = 0; i + 1 < PF; ++i) {
 #pragma unroll
-                for (int u = 0; u < NDMA; ++u) dma_one(kbase, koff, Ksm, i * BKV, i, u);
-                if (i + 1 < PF) {
+            for (int u = 0; u < NDMA; ++u) dma_one(kbase, koff, Ksm, i, nblk, i, u);
 #pragma unroll
-                    for (int u = 0; u < NDMA; ++u) dma_one(vbase, voff, Vsm, i * BKV, i, u);
-                }
-            }
+            for (int u = 0; u < NDMA; ++u) dma_one(vbase, voff, Vsm, i, nblk, i, u);
         }
-        bf16x8 qf[DSN];
+        bf16x8 qf[DSN];  // this wave's query rows (B operand of S^T: lane = query lq, d = 16 ds + 8 hi ..)
         {
             const bf16* qrow = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)(sp.qst + min(wq0 + lq, sq_len - 1)) * P.q_ss;
 #pragma unroll
@@ -264,75 +284,64 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
         if (CAUSAL && wq0 + QW - 1 + coff < 0) nact = 0;
 
         pp_barrier();
-        if (grpB) pp_barrier();  // group B starts one interval late ...
+        u32x4 kf[NF];  // K fragments of the NEXT C_QK (loop carried: requested beside the P V MFMAs of the tile before)
+        if (nact > 0) {
+            static_for_<0, NF>([&kf, ka0](auto fc) {
+                constexpr int f = decltype(fc)::value;
+                constexpr int ds = f >> 1, kb = f & 1;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[f]) : "v"(ka0 ^ (uint32_t)(ds << 5)), "n"(kb * 32 * PITCH));
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            static_for_<0, NF>([&kf](auto fc) { asm volatile("" : "+v"(kf[decltype(fc)::value])); });
+        }
+        if (grpB) pp_barrier();  // group B starts one segment late ...
+        if constexpr ((ABL & 16) != 0) {
+            if (grpB) __builtin_amdgcn_s_setprio(1);
+        }
+        PP_PHASE(2 + 4 * pass);
 
-        auto wait_k_next = [&](int j) {  // end of L_V(j): this wave's share of K(j + 1) has landed
-            if (j + PF - 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        auto wait_v_cur = [&](int j) {  // end of L_K(j): this wave's share of V(j) has landed
-            if (j + PF - 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-
-        int slot = 0;
+        int slot = 0;  // j % PF
         int j = 0;
         for (; j < nact; ++j) {
             const int kv0 = j * BKV;
-            const uint32_t soff = (uint32_t)(slot * TILE);
-            const int vslot = slot == 0 ? PF - 1 : slot - 1;       // slot of V(j + PF - 1) = slot of V(j - 1)
-            const bool v_more = j + PF - 1 < nblk, k_more = j + PF < nblk;
-            u32x4 kf[NF];             // K fragments
-            u32x2 vlo[NF], vhi[NF];   // V fragments (time-share the K fragments' registers: disjoint live ranges)
-            // ------------------------------------------------------------------ L_K
-            if constexpr (!(ABL & 8)) {
-                const uint32_t ka = ka0 + soff;
-                static_for_<0, NF>([&kf, ka](auto fc) {
-                    constexpr int f = decltype(fc)::value;
-                    constexpr int ds = f >> 1, kb = f & 1;
-                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[f]) : "v"(ka ^ (uint32_t)(ds << 5)), "n"(kb * 32 * PITCH));
-                });
+            const int pslot = slot == 0 ? PF - 1 : slot - 1;       // (j - 1) % PF: slot of V(j + PF - 1)
+            const int nslot = slot + 1 == PF ? 0 : slot + 1;       // (j + 1) % PF: slot of K(j + 1)
+            u32x2 vlo[NF], vhi[NF];   // V fragments (take over the K fragments' registers as those are consumed)
+            // ------------------------------------------------------------------ X(j): C_QK  (+ V(j) fragment reads, DMA of V(j + PF - 1))
+            if constexpr ((ABL & 32) != 0) __builtin_amdgcn_s_setprio(1);
+            if constexpr ((ABL & 64) != 0) {
+                if (grpB) __builtin_amdgcn_s_setprio(1);
             }
-            wait_v_cur(j);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            static_for_<0, NF>([&kf](auto fc) { asm volatile("" : "+v"(kf[decltype(fc)::value])); });
-            PP_STAMP();
-            pp_barrier();
-            PP_STAMP();
-            // ------------------------------------------------------------------ C_QK  (+ the DMA requests of V(j + PF - 1))
-            static_for_<0, DSN>([&](auto dc) {
-                constexpr int ds = decltype(dc)::value;
-                const bf16x8 k0 = __builtin_bit_cast(bf16x8, kf[2 * ds]), k1 = __builtin_bit_cast(bf16x8, kf[2 * ds + 1]);
-                if constexpr (ds == 0) {
-                    f32x16 z;
+            {
+                const uint32_t va = va0 + (uint32_t)(slot * TILE);
+                static_for_<0, DSN>([&](auto dc) {
+                    constexpr int ds = decltype(dc)::value;
+                    const bf16x8 k0 = __builtin_bit_cast(bf16x8, kf[2 * ds]), k1 = __builtin_bit_cast(bf16x8, kf[2 * ds + 1]);
+                    if constexpr (ds == 0) {
+                        f32x16 z;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ds], z, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ds], z, 0, 0, 0);
-                } else {
-                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ds], s0, 0, 0, 0);
-                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ds], s1, 0, 0, 0);
-                }
-                if constexpr (ds >= 1 && ds - 1 < NDMA && !(ABL & 1)) {
-                    if (v_more) dma_one(vbase, voff, Vsm, (j + PF - 1) * BKV, vslot, ds - 1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            PP_STAMP();
-            pp_barrier();
-            PP_STAMP();
-            // ------------------------------------------------------------------ L_V  (+ row max, rescale decision, P of the first 16 keys)
-            if constexpr (!(ABL & 8)) {
-                const uint32_t va = va0 + soff;
-                static_for_<0, NF>([&vlo, &vhi, va](auto fc) {
-                    constexpr int f = decltype(fc)::value;
-                    constexpr int ks = f / DBN, db = f % DBN;
-                    const uint32_t a = va ^ (uint32_t)(db << 6);
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[f]) : "v"(a), "n"(ks * 16 * PITCH));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[f]) : "v"(a), "n"(ks * 16 * PITCH + 8 * PITCH));
+                        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ds], z, 0, 0, 0);
+                        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ds], z, 0, 0, 0);
+                    } else {
+                        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ds], s0, 0, 0, 0);
+                        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ds], s1, 0, 0, 0);
+                    }
+                    static_for_<2 * ds, 2 * ds + 2>([&vlo, &vhi, va](auto fc) {
+                        constexpr int f = decltype(fc)::value;
+                        constexpr int ks = f / DBN, db = f % DBN;
+                        const uint32_t a = va ^ (uint32_t)(db << 6);
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[f]) : "v"(a), "n"(ks * 16 * PITCH));
+                        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[f]) : "v"(a), "n"(ks * 16 * PITCH + 8 * PITCH));
+                    });
+                    if constexpr (ds >= 1 && ds - 1 < NDMA && !(ABL & 1)) dma_one(vbase, voff, Vsm, j + PF - 1, nblk, pslot, ds - 1);
+                    if constexpr (ds >= 1 + DSN / 2 && ds - 1 - DSN / 2 < NDMA && !(ABL & 1))
+                        dma_one(kbase, koff, Ksm, j + PF - 1, nblk, pslot, ds - 1 - DSN / 2);
+                    __builtin_amdgcn_sched_barrier(0);
                 });
             }
-            float nm = 0.f;
+            // ------------------------------------------------------------------ X(j) tail: mask and row max (still beside the partner's Y)
+            float m_new = m_run;
             if constexpr (!(ABL & 4)) {
                 const bool need_mask = (kv0 + BKV > sk_len) || (CAUSAL && (kv0 + BKV - 1 > wq0 + coff));
                 if (need_mask) {
@@ -346,14 +355,25 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
                         s1[r] = (c + 32 > lim) ? -INFINITY : s1[r];
                     }
                 }
-                // row max over the lane's 32 keys (two chains), then across the two half-waves that share the query
+                // row max over the lane's 32 keys (two interleaved chains), then across the two half-waves that share the query
                 float mxa, mxb;
                 pp_max8x2<0>(s0, s1, mxa, mxb);
                 pp_max8x2<1>(s0, s1, mxa, mxb);
                 const float mb = pp_max2(mxa, mxb);
                 const uint32_t mu = __float_as_uint(mb);
                 const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-                const float m_new = pp_max3(m_run, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
+                m_new = pp_max3(m_run, __uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_X) : "memory");  // this wave's share of V(j + 1) has landed
+            PP_STAMP();
+            pp_barrier();
+            PP_STAMP();
+            // ------------------------------------------------------------------ Y(j): rescale decision, exponents, P of step 0
+            // Y is the long segment: its wave runs at priority 1, so the partner's X (priority 0, ~300 cycles of slack) is the one that waits
+            // at the arbitration -- with equal priorities the OLDER wave wins whatever it is doing (-6 % per tile, profiles r05 timeline).
+            __builtin_amdgcn_s_setprio(1);
+            float nm = 0.f;
+            if constexpr (!(ABL & 4)) {
                 // The running max only advances when some row's max grew by more than 2^kDefer (exp2 domain): otherwise this tile's
                 // probabilities are taken against the old max (bounded by 2^kDefer, invisible in O = sum(P V) / sum(P)).  At this point
                 // nothing is pending at the old scale except O and l themselves (P V of the previous tile is complete, its row sums
@@ -367,16 +387,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
                     m_run = m_new;
                 }
                 nm = -m_run * sl2;
-                // Exponents of the whole tile (32 independent FMAs), then the probabilities of the first 16-key step only (they feed the
-                // first DBN MFMAs of C_PV); the other steps are exponentiated in the shadow of the MFMAs, one group ahead of their pack, so
+                // Exponents of the whole tile (independent FMAs), then the probabilities of the first 16-key step only (they feed the first
+                // DBN MFMAs of C_PV); the other steps are exponentiated in the shadow of the MFMAs, one group ahead of their pack, so
                 // that no filler depends on a result of its own group (an in-order wave stalls on a dependent VALU / transcendental: the
-                // dependent form measured 71 cycles per MFMA group, the pipelined one fits the MFMA's 32).  P^T as B operands: the k slots
-                // of step ks = 2 kb + jj are the lane's scores 8 jj .. 8 jj + 7 of key block kb, in order.  Packed words and the exponent
-                // registers are pinned where they are produced (empty volatile asm): LLVM otherwise SINKS the chain behind the barrier.
+                // dependent form measured 71 cycles per MFMA group).  P^T as B operands: the k slots of step ks = 2 kb + jj are the
+                // lane's scores 8 jj .. 8 jj + 7 of key block kb, in order.  Packed words and the exponent registers are pinned where
+                // they are produced (empty volatile asm): LLVM otherwise SINKS the chain behind the barrier.
+                {
+                    const f32x2 sl22 = f32x2{sl2, sl2}, nm2 = f32x2{nm, nm};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    s0[r] = fmaf(s0[r], sl2, nm);
-                    s1[r] = fmaf(s1[r], sl2, nm);
+                    for (int r = 0; r < 16; r += 2) {  // v_pk_fma_f32: the head is issue bound, not shadowed by MFMAs
+                        f32x2 a = f32x2{s0[r], s0[r + 1]}, c = f32x2{s1[r], s1[r + 1]};
+                        a = __builtin_elementwise_fma(a, sl22, nm2);
+                        c = __builtin_elementwise_fma(c, sl22, nm2);
+                        s0[r] = a[0]; s0[r + 1] = a[1];
+                        s1[r] = c[0]; s1[r + 1] = c[1];
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(s0[r]), "+v"(s1[r]));
@@ -389,16 +415,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
                     pb[0][w] = u;
                 }
             }
-            wait_k_next(j);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // V(j) fragments are in their registers (requested a segment ago)
             static_for_<0, NF>([&vlo, &vhi](auto fc) { asm volatile("" : "+v"(vlo[decltype(fc)::value]), "+v"(vhi[decltype(fc)::value])); });
-            PP_STAMP();
-            pp_barrier();
-            PP_STAMP();
-            // ------------------------------------------------------------------ C_PV
-            // Fillers in FRONT of MFMA g (~5 VALU issues hide under one 32x32x16 MFMA, tools/mfma_filler_probe.hip), pairs p = 0 .. NPAIR - 1
-            // of scores of steps 1 .. KS - 1 in order:  exp2 of pair g  |  pack + row-sum adds of pair g - 1 (exponentiated one group
-            // earlier)  |  the row-sum adds of step 0 in the last groups  |  (first groups) the DMA requests of K(j + PF).
+            // ------------------------------------------------------------------ Y(j): C_PV
+            if constexpr ((ABL & 32) != 0) __builtin_amdgcn_s_setprio(1);
+            if constexpr ((ABL & 64) != 0) {
+                if (grpB) __builtin_amdgcn_s_setprio(0);
+            }
+            // Fillers in FRONT of MFMA g (~5 VALU issues hide under one 32x32x16 MFMA, tools/mfma_filler_probe.hip), pairs p = 0 .. 11 of
+            // scores of steps 1 .. KS - 1 in order:  exp2 of pair g  |  pack + row-sum adds of pair g - 1 (exponentiated one group earlier)
+            // |  the row-sum adds of step 0 in the last groups  |  behind the MFMA: the read of K(j + 1) fragment g, DMA of K(j + PF).
             {
                 float la = 0.f, lb = 0.f;
                 constexpr int PPG = (12 + NF - 1) / NF;  // score pairs per group: the 12 pairs of steps 1..3 over NF groups (1 / 2)
@@ -412,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
                     if (ks < 2) s0[8 * ks + e] = x;
                     else s1[8 * (ks - 2) + e] = x;
                 };
+                const uint32_t kan = ka0 + (uint32_t)(nslot * TILE);
                 static_for_<0, NF>([&](auto fc) {
                     constexpr int f = decltype(fc)::value;
                     constexpr int ks = f / DBN, db = f % DBN;
@@ -433,7 +460,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
                             asm volatile("v_add_f32 %0, %0, %1" : "+v"(lb) : "v"(x1));
                         }
                     }
-                    if constexpr (f >= NF - 4 && !(ABL & 2)) {  // step 0's eight probabilities (exponentiated in L_V): two adds in each of the last 4 groups
+                    if constexpr (f >= NF - 4 && !(ABL & 2)) {  // step 0's eight probabilities (exponentiated in X): two adds in each of the last 4 groups
                         constexpr int e = 2 * (f - (NF - 4));
                         asm volatile("v_add_f32 %0, %0, %1" : "+v"(la) : "v"(s0[e]));
                         asm volatile("v_add_f32 %0, %0, %1" : "+v"(lb) : "v"(s0[e + 1]));
@@ -441,36 +468,37 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
                     const bf16x8 va_ = join2(vlo[f], vhi[f]);
                     const bf16x8 pv = __builtin_bit_cast(bf16x8, u32x4{pb[ks][0], pb[ks][1], pb[ks][2], pb[ks][3]});
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va_, pv, oacc[db], 0, 0, 0);
-                    if constexpr (f < NDMA && !(ABL & 1)) {
-                        if (k_more) dma_one(kbase, koff, Ksm, (j + PF) * BKV, slot, f);
+                    {  // K(j + 1) fragment f (order of the next C_QK: d step f / 2, key block f % 2)
+                        constexpr int ds = f >> 1, kb = f & 1;
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf[f]) : "v"(kan ^ (uint32_t)(ds << 5)), "n"(kb * 32 * PITCH));
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 l_run += la + lb;
             }
+            __builtin_amdgcn_s_setprio(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_Y) : "memory");  // this wave's share of K(j + 2) has landed
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // K(j + 1) fragments are in their registers
+            static_for_<0, NF>([&kf](auto fc) { asm volatile("" : "+v"(kf[decltype(fc)::value])); });
             PP_STAMP();
             pp_barrier();
             PP_STAMP();
-            slot = (slot + 1 == PF) ? 0 : slot + 1;
+            slot = nslot;
         }
         for (; j < nblk; ++j) {  // idle part (causal: tiles above this wave's rows): keep the DMA shares and the barriers going
-            const int vslot = slot == 0 ? PF - 1 : slot - 1;
-            wait_v_cur(j);
-            pp_barrier();
-            if (j + PF - 1 < nblk) {
+            const int pslot = slot == 0 ? PF - 1 : slot - 1;
 #pragma unroll
-                for (int u = 0; u < NDMA; ++u) dma_one(vbase, voff, Vsm, (j + PF - 1) * BKV, vslot, u);
-            }
-            pp_barrier();
-            wait_k_next(j);
-            pp_barrier();
-            if (j + PF < nblk) {
+            for (int u = 0; u < NDMA; ++u) dma_one(vbase, voff, Vsm, j + PF - 1, nblk, pslot, u);
 #pragma unroll
-                for (int u = 0; u < NDMA; ++u) dma_one(kbase, koff, Ksm, (j + PF) * BKV, slot, u);
-            }
+            for (int u = 0; u < NDMA; ++u) dma_one(kbase, koff, Ksm, j + PF - 1, nblk, pslot, u);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_X) : "memory");
             pp_barrier();
-            slot = (slot + 1 == PF) ? 0 : slot + 1;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_Y) : "memory");
+            pp_barrier();
+            slot = slot + 1 == PF ? 0 : slot + 1;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-fetches past the end have landed before the next pass reuses the rings
+        PP_PHASE(3 + 4 * pass);
         if (!grpB) pp_barrier();  // ... and group A waits for it at the end: every wave has passed its last LDS read
         if constexpr (TL) {
             PP_STAMP();
@@ -512,6 +540,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
                 }
             if (qrow < SqE && lsebase && hi == 0) lsebase[qrow] = (valid && l > 0.f) ? (m_run * P.scale + logf(l)) : 0.f;
         }
+        PP_PHASE(4 + 4 * pass);
     }  // pass
 }
 
@@ -533,18 +562,22 @@ __attribute__((visibility("hidden"))) int dllm_launch_attn_fwd_pp(const AttnPara
 #ifdef DLLM_BENCH_MODES
     if (P.delta != nullptr && D == 128 && causal) {  // timeline diagnostic; bits 8.. of `causal` = ablation
         switch (causal >> 8) {
-            case 0: return launch_pp<128, true, 2, true, 0>(P, stream);
-            case 1: return launch_pp<128, true, 2, true, 1>(P, stream);
-            case 2: return launch_pp<128, true, 2, true, 2>(P, stream);
-            case 3: return launch_pp<128, true, 2, true, 3>(P, stream);
-            case 4: return launch_pp<128, true, 2, true, 4>(P, stream);
-            case 7: return launch_pp<128, true, 2, true, 7>(P, stream);
-            case 8: return launch_pp<128, true, 2, true, 8>(P, stream);
-            case 15: return launch_pp<128, true, 2, true, 15>(P, stream);
+            case 0: return launch_pp<128, true, 3, true, 0>(P, stream);
+            case 1: return launch_pp<128, true, 3, true, 1>(P, stream);
+            case 2: return launch_pp<128, true, 3, true, 2>(P, stream);
+            case 3: return launch_pp<128, true, 3, true, 3>(P, stream);
+            case 4: return launch_pp<128, true, 3, true, 4>(P, stream);
+            case 7: return launch_pp<128, true, 3, true, 7>(P, stream);
+            case 8: return launch_pp<128, true, 3, true, 8>(P, stream);
+            case 15: return launch_pp<128, true, 3, true, 15>(P, stream);
+            case 16: return launch_pp<128, true, 3, true, 16>(P, stream);
+            case 32: return launch_pp<128, true, 3, true, 32>(P, stream);
+            case 64: return launch_pp<128, true, 3, true, 64>(P, stream);
+            case 128: return launch_pp<128, true, 3, true, 128>(P, stream);
             default: return DLLM_ERR_SHAPE;
         }
     }
 #endif
-    if (D == 128) return causal ? launch_pp<128, true, 2>(P, stream) : launch_pp<128, false, 2>(P, stream);
-    return causal ? launch_pp<64, true, 2>(P, stream) : launch_pp<64, false, 2>(P, stream);
+    if (D == 128) return causal ? launch_pp<128, true, 3>(P, stream) : launch_pp<128, false, 3>(P, stream);
+    return causal ? launch_pp<64, true, 3>(P, stream) : launch_pp<64, false, 3>(P, stream);
 }
