@@ -207,6 +207,22 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
         va0 = lds_addr32(Vsm) + (uint32_t)((4 * hi + (t >> 2)) * PITCH + 32 * gb + 8 * (t & 3) + (swg << 6));
     }
 
+    const bf16* qhead = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)sp.qst * P.q_ss;
+    // first tiles of a pass (K / V tiles 0 .. PF - 2 of the head) and this wave's query rows (B operand of S^T: lane = query lq, d = 16 ds + 8 hi ..)
+    bf16x8 qf[DSN];
+    auto request_pass = [&](int qblk_, int nblk_) {
+        for (int i = 0; i + 1 < PF; ++i) {
+#pragma unroll
+            for (int u = 0; u < NDMA; ++u) dma_one(kbase, koff, Ksm, i, nblk_, i, u);
+#pragma unroll
+            for (int u = 0; u < NDMA; ++u) dma_one(vbase, voff, Vsm, i, nblk_, i, u);
+        }
+        const bf16* qrow = qhead + (int64_t)min(qblk_ * BQ + wave * QW + lq, sq_len - 1) * P.q_ss;
+#pragma unroll
+        for (int ds = 0; ds < DSN; ++ds) qf[ds] = ld_bf16x8(qrow + ds * 16 + hi * 8);
+    };
+    bool requested = false;  // the pass's first tiles / query rows were requested in front of the previous pass's store tail
+
     const int npass = (CAUSAL && nqb - 1 - bm.r != bm.r) ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
         const int qblk = CAUSAL ? (pass == 0 ? nqb - 1 - bm.r : bm.r) : bm.r;
@@ -254,20 +270,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
         constexpr int YOUNGER_X = (1 + 2 * (PF - 2)) * NDMA;  // end of X(j): V(j + 1) landed <=> at most K(j + 1) .. K(j + PF - 1) outstanding
         constexpr int YOUNGER_Y = 2 * (PF - 3) * NDMA;        // end of Y(j): K(j + 2) landed <=> at most V(j + 3) .. K(j + PF - 1) outstanding
         static_assert(PF >= 3, "K(j + 2) is requested in X(j + 3 - PF)");
-        for (int i = 0; i + 1 < PF; ++i) {
+        if (!requested) request_pass(qblk, nblk);
 #pragma unroll
-            for (int u = 0; u < NDMA; ++u) dma_one(kbase, koff, Ksm, i, nblk, i, u);
-#pragma unroll
-            for (int u = 0; u < NDMA; ++u) dma_one(vbase, voff, Vsm, i, nblk, i, u);
-        }
-        bf16x8 qf[DSN];  // this wave's query rows (B operand of S^T: lane = query lq, d = 16 ds + 8 hi ..)
-        {
-            const bf16* qrow = P.q + (int64_t)b * P.q_sb + (int64_t)h * P.q_sh + (int64_t)(sp.qst + min(wq0 + lq, sq_len - 1)) * P.q_ss;
-#pragma unroll
-            for (int ds = 0; ds < DSN; ++ds) qf[ds] = ld_bf16x8(qrow + ds * 16 + hi * 8);
-#pragma unroll
-            for (int ds = 0; ds < DSN; ++ds) pin_loaded(qf[ds]);
-        }
+        for (int ds = 0; ds < DSN; ++ds) pin_loaded(qf[ds]);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // first tiles landed (this wave's shares); the barrier below publishes them
         f32x16 oacc[DBN];
 #pragma unroll
@@ -512,6 +517,18 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
                     dst[i] = (i < (int)((tl_addr - base) >> 3)) ? (((uint64_t)w[1] << 32) | w[0]) : 0ull;
                 }
                 tl_on = false;
+            }
+        }
+
+        // ---- second pass of a causal pair: its first tiles and query rows are requested NOW (every wave is past its last LDS read, the
+        // query registers are free), so the ~9.5 k cycles of prologue latency run under this pass's store tail
+        requested = false;
+        if (CAUSAL && pass + 1 < npass) {
+            const int qblk_n = bm.r, q0n = qblk_n * BQ;
+            const int kv_end_n = min(sk_len, q0n + BQ + coff);
+            if (q0n < sq_len && kv_end_n > 0) {
+                request_pass(qblk_n, (kv_end_n + BKV - 1) / BKV);
+                requested = true;
             }
         }
 
