@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--no-pack", action="store_true", help="A/B knob: one GEMM per projection instead of packed q|k|v and gate|up")
     ap.add_argument("--unfused-ce", action="store_true", help="A/B knob: lm_head + CE through the full fp32 logits")
     ap.add_argument("--no-configs", action="store_true", help="skip the short config-2 / config-5 legs (N = 1 only)")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the secondary ragged (varlen) training leg (S ~ U{S/2..S}, seqlens passed)")
+    ap.add_argument("--ragged-steps", type=int, default=3)
     ap.add_argument("--sharded-grad", action="store_true",
                     help="N>1: reduce-scatter + sharded AdamW + all-gather (distributed.ShardedGradAdamW) instead of DDP all-reduce")
     return ap.parse_args()
@@ -106,6 +108,20 @@ def cpu_baseline(seq_len, budget_s=60.0):
         llm_ref.decoder_layer(x, sd, "", cfg, cos, sin, pos, mask).square().mean().backward()
 
     t_layer = piece("layer", layer)
+    # the same layer in bf16 (SURVEY §8d asks for fp32 AND bf16): bf16 weights / activations, torch's CPU bf16 GEMMs
+    t_layer_bf16 = None
+    try:
+        sdb = {k: v.detach().to(torch.bfloat16).requires_grad_(True) for k, v in sd.items()}
+        maskb = mask.to(torch.bfloat16)
+
+        def layer_bf16():
+            x = torch.randn(1, S, H).to(torch.bfloat16).requires_grad_(True)
+            llm_ref.decoder_layer(x, sdb, "", cfg, cos, sin, pos, maskb).float().square().mean().backward()
+
+        t_layer_bf16 = piece("layer_bf16", layer_bf16)
+        del sdb, maskb
+    except Exception:
+        t_layer_bf16 = None
     w = (torch.randn(32008, H) * 0.02).requires_grad_(True)
     h = torch.randn(S, H, requires_grad=True)
     lab = torch.randint(0, 32008, (S,))
@@ -136,6 +152,8 @@ def cpu_baseline(seq_len, budget_s=60.0):
         f"{n}: {'median of 3 runs' if r == 3 else f'{r} run (three more would not fit the {budget_s:.0f} s budget)'}" for n, r in reps_used.items())
     return dict(value=1.0 / t_sample, unit="samples/s", cores=torch.get_num_threads(), kind="port",
                 denoise_steps_per_s=round(1.0 / t_unet2, 4), timing=timing, runs_per_piece=reps_used,
+                decoder_layer_fwd_bwd_s=dict(fp32=round(t_layer, 3), bf16=None if t_layer_bf16 is None else round(t_layer_bf16, 3)),
+                value_bf16_layers=None if t_layer_bf16 is None else 1.0 / (t_sample - 32 * t_layer + 32 * t_layer_bf16),
                 sample=f"oracle ports (CLIP: installed transformers class), fp32: decoder layer fwd+bwd B=1 S={S} ({t_layer:.2f} s, x32) + lm_head/CE "
                        f"({t_head:.2f} s) + CLIP-L/14 fwd ({'n/a' if t_clip is None else f'{t_clip:.2f} s'}, x{K}) + SD-2.1 UNet CFG "
                        f"step batch 2 ({t_unet2:.2f} s = the CPU denoise step; x{K} stands for fwd+dgrad of {K} dream images); "
@@ -247,8 +265,8 @@ def main():
         else:
             batch = make_interleaved_batch(a.batch, a.seq_len, a.images_per_sample, seed=1234 + rank, device=dev)
 
-        def step():
-            out = ddp(**batch, return_dict=True)
+        def step(b=None):
+            out = ddp(**(batch if b is None else b), return_dict=True)
             out.loss.backward()
             opt.step()
             opt.zero_grad(set_to_none=True)
@@ -334,6 +352,53 @@ def main():
             comm=comm,
         )
 
+    # ------------------------------------------------------------------ secondary leg: ragged documents (SURVEY §8d "Synthetic inputs")
+    # S ~ U{S/2 .. S} per document, right-padded to S, `seqlens` passed: the varlen path of modeling_dreamllm.py:521-545 (per-row spans in
+    # the attention kernels, loss on the labelled rows).  Same model / optimizer state; 1 warm-up + `--ragged-steps` timed steps.
+    ragged = None
+    if not a.no_train and not a.no_ragged and not tiny:
+        try:
+            rb = make_interleaved_batch(a.batch, a.seq_len, a.images_per_sample, seed=4321 + rank, device=dev, ragged=True)
+            lens = rb["attention_mask"].sum(1).tolist()
+            labr = rb["labels"]
+            n_lab = int((labr[:, 1:] != -100).sum().item())
+            step(rb)                                     # warm-up on the new shapes (kernel choices, allocator)
+            ops.GEMM_PROFILE = None
+            nlaunch = 1400
+            ops.prealloc_gemm_events(2 * nlaunch * a.ragged_steps + 64)
+            D.synchronize()
+            torch.cuda.synchronize()
+            ops.GEMM_PROFILE = []
+            t0 = time.perf_counter()
+            for _ in range(a.ragged_steps):
+                out_r = step(rb)
+            torch.cuda.synchronize()
+            D.synchronize()
+            dtr = D.max_over_ranks(time.perf_counter() - t0)
+            profr, ops.GEMM_PROFILE = ops.GEMM_PROFILE, None
+            gs = sum(f for _, _, f, _ in profr)
+            tsr = sum(s_.elapsed_time(e_) for s_, e_, _, _ in profr) * 1e-3
+            # algorithmic FLOPs from the ACTUAL lengths: 3 x fwd; fwd per token = 32 layers x (404.8 MFLOP linear +
+            # 2 * L * d causal attention) ; lm_head on the labelled rows; per image the CLIP / UNet / projector terms of the dense sample
+            per_tok_lin = 32 * 404.8e6
+            fl = sum(3 * L * (per_tok_lin + 32 * 2 * L * 4096) for L in lens) + 3 * FLOPS_LM_HEAD_TOKEN * n_lab \
+                + a.batch * a.images_per_sample * (0.162e12 + 1.61e12 + 3 * (2.15e9 + 0.54e9))
+            tokens = sum(lens)
+            ragged = dict(metric="interleaved train samples/sec, ragged documents (S ~ U{S/2..S}, right-padded, seqlens passed)",
+                          value=round(world * a.batch * a.ragged_steps / dtr, 4), unit="samples/s", steps=a.ragged_steps,
+                          ms_per_step=round(1e3 * dtr / a.ragged_steps, 3), tokens_per_s=round(world * tokens * a.ragged_steps / dtr, 1),
+                          mean_len=round(tokens / a.batch, 1), min_len=int(min(lens)), max_len=int(max(lens)), loss=float(out_r.loss.item()),
+                          flops_per_step=fl,
+                          e2e_frac_mfma_peak=round(fl * a.ragged_steps / dtr / (PEAK_BF16_TFLOPS * 1e12), 4),
+                          roofline=dict(bound="mfma", kernel="bf16 MFMA GEMM family (same kernels as the dense leg; M = the padded token count)",
+                                        achieved=round(gs / tsr / 1e12, 1) if tsr > 0 else None, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                                        frac=round(gs / tsr / 1e12 / PEAK_BF16_TFLOPS, 4) if tsr > 0 else None, traffic=None,
+                                        launches_per_step=len(profr) // max(a.ragged_steps, 1), time_share_of_step=round(tsr / dtr, 4),
+                                        note="GEMMs run on the padded [B, S] token grid (executed FLOPs of the launches, as in the dense "
+                                             "leg); e2e_frac_mfma_peak beside it uses the algorithmic FLOPs of the actual lengths"))
+        except Exception as ex:  # secondary leg: never lose the headline line
+            ragged = {"error": repr(ex)}
+
     # ------------------------------------------------------------------ the other BASELINE.json configs (N = 1 only, short)
     configs = None
     if world == 1 and not tiny and not a.no_configs:
@@ -382,6 +447,7 @@ def main():
             "rccl_ranks": rccl_ranks,
             "comm_exposed_ms": (train.get("comm") or {}).get("comm_exposed_ms"),
             "comm": train.get("comm"),
+            "train_ragged": ragged,
             "denoise": denoise,
             "configs": configs,
         }

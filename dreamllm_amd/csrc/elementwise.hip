@@ -771,10 +771,10 @@ int dllm_adamw_multi(void* const* p, const void* const* g, void* const* m, void*
              reinterpret_cast<uintptr_t>(v[i])) & 15)
             return DLLM_ERR_ALIGN;
     }
-    for (int i0 = 0; i0 < count; i0 += MT_MAX) {
+    for (int i = 0; i < count;) {  // `i` is the consumed index: empty tensors are skipped without being revisited by the next batch
         MtAdamTable T{};
         int chunks = 0, k = 0;
-        for (int i = i0; i < count && k < MT_MAX; ++i) {
+        for (; i < count && k < MT_MAX; ++i) {
             if (n[i] == 0) continue;
             T.p[k] = (bf16*)p[i]; T.g[k] = (const bf16*)g[i]; T.m[k] = (bf16*)m[i]; T.v[k] = (bf16*)v[i];
             T.n8[k] = n[i] / 8;
@@ -806,10 +806,10 @@ int dllm_sumsq_multi(const void* const* x, const int64_t* n, int count, float* p
     for (int i = 0; i < count; ++i)
         if (n[i] < 0 || (n[i] & 7) || (reinterpret_cast<uintptr_t>(x[i]) & 15)) return DLLM_ERR_ALIGN;
     int64_t done = 0;
-    for (int i0 = 0; i0 < count; i0 += MT_MAX) {
+    for (int i = 0; i < count;) {  // consumed index, as in dllm_adamw_multi
         MtSumsqTable T{};
         int chunks = 0, k = 0;
-        for (int i = i0; i < count && k < MT_MAX; ++i) {
+        for (; i < count && k < MT_MAX; ++i) {
             if (n[i] == 0) continue;
             T.x[k] = (const bf16*)x[i];
             T.n8[k] = n[i] / 8;

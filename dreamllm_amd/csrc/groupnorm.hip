@@ -28,6 +28,14 @@ __global__ void gn_partial_kernel(const bf16* __restrict__ x, const bf16* __rest
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    // MODE 0: sums of (x - pivot), pivot = the (image, group)'s first element: with E[x^2] - mean^2 on raw values a group whose mean is
+    // 100 x its standard deviation (real SD activations get there) loses four digits of the variance in fp32
+    float pv[8];
+    if (MODE == 0) {
+        const int cpg = C / G;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = (float)x[(int64_t)n * HW * C + ((cv * 8 + e) / cpg) * cpg];
+    }
     float mu[8], rs[8], ga[8], be[8];
     if (MODE == 1) {
         const int cpg = C / G;
@@ -47,7 +55,7 @@ __global__ void gn_partial_kernel(const bf16* __restrict__ x, const bf16* __rest
             if (MODE == 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float f = (float)v[e];
+                    const float f = (float)v[e] - pv[e];
                     s1[e] += f;
                     s2[e] += f * f;
                 }
@@ -100,9 +108,10 @@ template <int MODE>
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part, const bf16* __restrict__ gamma,
                                                          const bf16* __restrict__ beta, float* __restrict__ out1,
                                                          float* __restrict__ out2, float* __restrict__ ab, int nchunks, int HW,
-                                                         int C, int G, float eps) {
+                                                         int C, int G, float eps, const bf16* __restrict__ x) {
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int cpg = C / G;
+    const float pivot = (MODE == 0) ? (float)x[(int64_t)n * HW * C + g * cpg] : 0.f;  // as gn_partial_kernel<0>
     float s1 = 0.f, s2 = 0.f;
     const int items = nchunks * cpg;
     for (int i = threadIdx.x; i < items; i += 64) {
@@ -115,8 +124,9 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     s2 = wave_sum(s2);
     const float cnt = (float)HW * (float)cpg;
     if (MODE == 0) {
-        const float mean = s1 / cnt;
-        const float var = fmaxf(s2 / cnt - mean * mean, 0.f);
+        const float dm = s1 / cnt;                                   // mean - pivot
+        const float mean = pivot + dm;
+        const float var = fmaxf(s2 / cnt - dm * dm, 0.f);
         const float rstd = rsqrtf(var + eps);
         if (threadIdx.x == 0) {
             out1[n * G + g] = mean;
@@ -170,6 +180,8 @@ __global__ __launch_bounds__(1024) void gn_small_kernel(const bf16* __restrict__
     const bool live = r < R;
     const int64_t base = (int64_t)n * HW * C + g * cpg + 2 * j;
     const int64_t stride = (int64_t)R * C;
+    // sums of (x - pivot), pivot = the slice's first element (see gn_partial_kernel): no cancellation when |mean| >> std
+    const float pivot = (float)x[(int64_t)n * HW * C + g * cpg];
     float s1 = 0.f, s2 = 0.f;
     if (live) {
         const bf16* px = x + base + (int64_t)r * C;
@@ -177,14 +189,14 @@ __global__ __launch_bounds__(1024) void gn_small_kernel(const bf16* __restrict__
         for (; p + 3 * R < HW; p += 4 * R, px += 4 * stride) {  // four independent loads in flight per thread
             const bf16x2 v0 = *reinterpret_cast<const bf16x2*>(px), v1 = *reinterpret_cast<const bf16x2*>(px + stride);
             const bf16x2 v2 = *reinterpret_cast<const bf16x2*>(px + 2 * stride), v3 = *reinterpret_cast<const bf16x2*>(px + 3 * stride);
-            const float a0 = (float)v0[0], b0 = (float)v0[1], a1 = (float)v1[0], b1 = (float)v1[1];
-            const float a2 = (float)v2[0], b2 = (float)v2[1], a3 = (float)v3[0], b3 = (float)v3[1];
+            const float a0 = (float)v0[0] - pivot, b0 = (float)v0[1] - pivot, a1 = (float)v1[0] - pivot, b1 = (float)v1[1] - pivot;
+            const float a2 = (float)v2[0] - pivot, b2 = (float)v2[1] - pivot, a3 = (float)v3[0] - pivot, b3 = (float)v3[1] - pivot;
             s1 += (a0 + b0) + (a1 + b1) + (a2 + b2) + (a3 + b3);
             s2 += (a0 * a0 + b0 * b0) + (a1 * a1 + b1 * b1) + (a2 * a2 + b2 * b2) + (a3 * a3 + b3 * b3);
         }
         for (; p < HW; p += R, px += stride) {
             const bf16x2 v = *reinterpret_cast<const bf16x2*>(px);
-            const float a = (float)v[0], b = (float)v[1];
+            const float a = (float)v[0] - pivot, b = (float)v[1] - pivot;
             s1 += a + b;
             s2 += a * a + b * b;
         }
@@ -192,8 +204,9 @@ __global__ __launch_bounds__(1024) void gn_small_kernel(const bf16* __restrict__
     s1 = block_sum<16>(s1, red);
     s2 = block_sum<16>(s2, red + 16);
     const float cnt = (float)HW * (float)cpg;
-    const float mean = s1 / cnt;
-    const float rstd = rsqrtf(fmaxf(s2 / cnt - mean * mean, 0.f) + eps);
+    const float dm = s1 / cnt;
+    const float mean = pivot + dm;
+    const float rstd = rsqrtf(fmaxf(s2 / cnt - dm * dm, 0.f) + eps);
     if (threadIdx.x == 0) {
         mean_o[n * G + g] = mean;
         rstd_o[n * G + g] = rstd;
@@ -247,6 +260,7 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
     const int64_t base = (int64_t)n * HW * C + g * cpg + 2 * j;
     const int64_t stride = (int64_t)R * C;
     unsigned* slot = sync + (int64_t)grp * 32;
+    const float pivot = (float)x[(int64_t)n * HW * C + g * cpg];  // the same pivot in all S blocks of the slice (gn_small_kernel)
     unsigned f0 = 0;
     if (threadIdx.x == 0) {
         f0 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -259,14 +273,14 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
         for (; p + 3 * R < p1; p += 4 * R, px += 4 * stride) {
             const bf16x2 v0 = *reinterpret_cast<const bf16x2*>(px), v1 = *reinterpret_cast<const bf16x2*>(px + stride);
             const bf16x2 v2 = *reinterpret_cast<const bf16x2*>(px + 2 * stride), v3 = *reinterpret_cast<const bf16x2*>(px + 3 * stride);
-            const float a0 = (float)v0[0], b0 = (float)v0[1], a1 = (float)v1[0], b1 = (float)v1[1];
-            const float a2 = (float)v2[0], b2 = (float)v2[1], a3 = (float)v3[0], b3 = (float)v3[1];
+            const float a0 = (float)v0[0] - pivot, b0 = (float)v0[1] - pivot, a1 = (float)v1[0] - pivot, b1 = (float)v1[1] - pivot;
+            const float a2 = (float)v2[0] - pivot, b2 = (float)v2[1] - pivot, a3 = (float)v3[0] - pivot, b3 = (float)v3[1] - pivot;
             s1 += (a0 + b0) + (a1 + b1) + (a2 + b2) + (a3 + b3);
             s2 += (a0 * a0 + b0 * b0) + (a1 * a1 + b1 * b1) + (a2 * a2 + b2 * b2) + (a3 * a3 + b3 * b3);
         }
         for (; p < p1; p += R, px += stride) {
             const bf16x2 v = *reinterpret_cast<const bf16x2*>(px);
-            const float a = (float)v[0], b = (float)v[1];
+            const float a = (float)v[0] - pivot, b = (float)v[1] - pivot;
             s1 += a + b;
             s2 += a * a + b * b;
         }
@@ -310,6 +324,9 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
         tot[0] = t1;
         tot[1] = t2;
         alone = ok ? 0 : 1;
+        // the fallback changes the fp32 summation order of this (image, group): it is COUNTED in word 31 of the slot, so a caller (and
+        // the tests) can see that it happened instead of trusting that it does not
+        if (!ok) __hip_atomic_fetch_add(slot + 31, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (alone) {   // (uniform) statistics over ALL pixels of the slice, by this block alone
@@ -318,7 +335,7 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
             const bf16* px = x + base + (int64_t)r * C;
             for (int p = r; p < HW; p += R, px += stride) {
                 const bf16x2 v = *reinterpret_cast<const bf16x2*>(px);
-                const float a = (float)v[0], b = (float)v[1];
+                const float a = (float)v[0] - pivot, b = (float)v[1] - pivot;
                 a1 += a + b;
                 a2 += a * a + b * b;
             }
@@ -333,8 +350,9 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
         __syncthreads();
     }
     const float cnt = (float)HW * (float)cpg;
-    const float mean = tot[0] / cnt;
-    const float rstd = rsqrtf(fmaxf(tot[1] / cnt - mean * mean, 0.f) + eps);
+    const float dm = tot[0] / cnt;
+    const float mean = pivot + dm;
+    const float rstd = rsqrtf(fmaxf(tot[1] / cnt - dm * dm, 0.f) + eps);
     if (threadIdx.x == 0 && part == 0) {
         mean_o[n * G + g] = mean;
         rstd_o[n * G + g] = rstd;
@@ -466,7 +484,7 @@ int dllm_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void*
     hipLaunchKernelGGL(gn_partial_kernel<0>, dim3(nchunks, NB), dim3(block), lds, s, (const bf16*)x, nullptr, nullptr, nullptr,
                        nullptr, nullptr, part, HW, C, G, ppc, 0);
     hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3(NB * G), dim3(64), 0, s, part, (const bf16*)gamma, (const bf16*)beta, mean,
-                       rstd, ab, nchunks, HW, C, G, eps);
+                       rstd, ab, nchunks, HW, C, G, eps, (const bf16*)x);
     const int64_t tv = (int64_t)NB * HW * (C / 8);
     int grid = (int)((tv + 255) / 256 > 8192 ? 8192 : (tv + 255) / 256);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, ab, (bf16*)y, tv, HW, C, act);
@@ -502,7 +520,7 @@ int dllm_groupnorm_bwd(const void* dy, const void* x, const void* gamma, const v
     hipLaunchKernelGGL(gn_partial_kernel<1>, dim3(nchunks, NB), dim3(block), lds, s, (const bf16*)x, (const bf16*)dy, mean, rstd,
                        (const bf16*)gamma, (const bf16*)beta, part, HW, C, G, ppc, act);
     hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(NB * G), dim3(64), 0, s, part, nullptr, nullptr, c1, c2, nullptr, nchunks, HW,
-                       C, G, 0.f);
+                       C, G, 0.f, (const bf16*)nullptr);
     const int64_t tv = (int64_t)NB * HW * (C / 8);
     int grid = (int)((tv + 255) / 256 > 8192 ? 8192 : (tv + 255) / 256);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, mean, rstd, c1, c2,

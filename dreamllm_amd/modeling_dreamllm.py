@@ -1096,7 +1096,9 @@ class DreamLLMForCausalMLM(DreamLLMPreTrainedModel):
         else:
             vm_term = vm_loss * self.loss_weight_vm
         loss = (vm_term + lm_term) / loss_scale
-        if self._loss_scale_twice:
+        # The reference's SDXL model file divides by loss_scale a second time (modeling_dreamllm_sdxl.py:1485-1487).  Reproduced by default
+        # for that class (`_loss_scale_twice`), and switchable per model: `config.loss_scale_twice = False` gives the single division.
+        if getattr(self.config, "loss_scale_twice", self._loss_scale_twice):
             loss = loss / loss_scale
         if not torch.is_tensor(loss):
             loss = None if labels is None and not self.training else torch.as_tensor(loss, device=hidden_states.device)

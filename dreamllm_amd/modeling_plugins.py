@@ -498,9 +498,12 @@ class StableDiffusionHead(MultimodalHead):
         # ONE host conversion of the schedule (a device tensor would cost a sync per element); without micro-conditioning the table
         # depends on (schedule, batch) only and is kept across calls
         ts_host = tuple(float(t) for t in (timesteps.tolist() if torch.is_tensor(timesteps) else timesteps))
-        # (weights replaced in place -- load_state_dict, .to() -- bump the tensor version / identity and drop the table)
-        w_sig = tuple((id(p), p._version) for p in self.unet.time_embedding.parameters()) + \
-            tuple((id(r.time_emb_proj.weight), r.time_emb_proj.weight._version) for r in self.unet._resnets())
+        # every parameter the table is computed from -- time-embedding MLP, each ResBlock's time_emb_proj weight AND bias -- with its
+        # storage pointer, dtype and device beside identity / version: `module.to()` swaps `.data` without touching either
+        def _sig(p):
+            return (id(p), p._version, p.data_ptr(), p.dtype, str(p.device))
+        w_sig = tuple(_sig(p) for p in self.unet.time_embedding.parameters()) + \
+            tuple(_sig(p) for r in self.unet._resnets() for p in r.time_emb_proj.parameters())
         tb_key = (ts_host, 2 * B, w_sig)
         tb_cache = getattr(self, "_time_bias_cache", None)
         if addk is None and tb_cache is not None and tb_cache[0] == tb_key:

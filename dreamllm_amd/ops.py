@@ -1210,6 +1210,12 @@ def _gn_sync(device):
     return b
 
 
+def gn_split_fallbacks(device):
+    """How often a block of the split GroupNorm gave up on its partners and computed its slice alone (word 31 of every slot of every
+    sync buffer of `device`): 0 unless the GPU is shared with another process."""
+    return sum(int(b.view(-1, 32)[:, 31].sum()) for (dev, _), b in _GN_SYNC.items() if dev == device)
+
+
 def groupnorm_fwd(x, gamma, beta, G, eps, act):
     _need_gpu(x, gamma, beta)
     _bf16(x, gamma, beta)

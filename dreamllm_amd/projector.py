@@ -37,7 +37,7 @@ class BaseProjector(nn.Module):
                 logger.info(f"loading `BaseProjector` from {model_name_or_path}...")
                 self.load_state_dict(torch.load(model_name_or_path, map_location="cpu"))
                 return True
-            # HACK: For compatibility
+            # older checkpoints: the bare projector's state dict under a `.pt` name
             if check_path_and_file(model_name_or_path, f"{self.save_model_name}_projector.pt"):
                 logger.info(f"loading `BaseProjector` from {model_name_or_path}...")
                 self.projector.load_state_dict(torch.load(model_name_or_path, map_location="cpu"))
@@ -45,7 +45,7 @@ class BaseProjector(nn.Module):
         return False
 
     def forward(self, features) -> list:
-        # NOTE return a list to be compatible with models using multiple paths
+        # subclasses return a LIST of feature tensors (one per path), as their callers index it
         pass
 
     @property

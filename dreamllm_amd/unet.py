@@ -199,7 +199,11 @@ class GEGLU(nn.Module):
         # inference / denoising loop: projection + GEGLU in one launch.  In the loop's graph the fused form wins at every level but
         # one, where it ties (UNet batch 16: 64 x 64 level 286 us against 243 + ~120 us for GEMM + element-wise pass; 32 x 32 level
         # 213 against 172 + ~40 us; profiles/r04_unet_gemm_b16.log, r04_denoise_b8_launch_table.txt).
-        if not (torch.is_grad_enabled() and x.requires_grad) and x.numel() // x.shape[-1] <= GEGLU_FUSED_MAX_ROWS:
+        # (forward-only: taken only when NOTHING it touches needs a gradient -- a trainable `proj` behind a frozen input would otherwise
+        # silently receive none)
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or self.proj.weight.requires_grad or
+                                                  (self.proj.bias is not None and self.proj.bias.requires_grad))
+        if not needs_grad and x.numel() // x.shape[-1] <= GEGLU_FUSED_MAX_ROWS:
             y = ops.linear_geglu(x, self.proj.weight, self.proj.bias)
             if y is not None:
                 return y

@@ -60,7 +60,9 @@ int dllm_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void*
 /* Single-launch GroupNorm(+SiLU) spread over 4 blocks per (image, group) for tiny batches (the UNet inside the denoising loop at batch
  * 2: 64 (image, group) pairs on 256 CUs).  `sync`: caller-owned int32[>= NB*G*32], zero before the first use, left consistent by every
  * launch (one buffer per stream in flight).  Eligible when NB*HW*C <= 2^23, HW >= 1024, HW % 4 == 0, NB*G*4 <= 512; otherwise
- * DLLM_ERR_SHAPE and the caller uses dllm_groupnorm_fwd.  Same results as dllm_groupnorm_fwd up to fp32 summation order. */
+ * DLLM_ERR_SHAPE and the caller uses dllm_groupnorm_fwd.  Same results as dllm_groupnorm_fwd up to fp32 summation order.  Word 31 of
+ * an (image, group) slot counts how often a block gave up waiting for its partners (~2 ms) and computed the slice's statistics alone
+ * (never wrong, but a different fp32 summation order): 0 on a GPU this process has to itself. */
 int dllm_groupnorm_fwd_split(const void* x, const void* gamma, const void* beta, void* y, float* mean, float* rstd, int* sync,
                              int NB, int HW, int C, int G, float eps, int act, void* stream);
 int dllm_groupnorm_bwd(const void* dy, const void* x, const void* gamma, const void* beta, const float* mean, const float* rstd,

@@ -59,12 +59,15 @@ def bound(err_ref, slack=SLACK):
     return slack * err_ref + FLOOR
 
 
-# Yard-sticks taken under torch.autocast (the SDXL head: the reference cannot run in plain bf16) come from a HIGHER
-# precision program than "the reference in bf16": autocast keeps GroupNorm / LayerNorm / softmax in fp32 and hands fp32 results to
-# the next matmul, this implementation stores every intermediate in bf16.  Its gradient checks therefore sit at 1.05-1.2x that
-# yard-stick by construction, and a re-association anywhere upstream (a different split-K factor, a different kernel family) moves
-# a tiny-model gradient error by a few percent: round 3 measured 1.11x, round 4's kernels 1.19x on the same check.  Those checks
-# -- and only those -- take this documented slack; every measured pair still lands in the parity report with its bound.
+# The SDXL head's TINY-model gradient checks (tests/golden/sdxl_head.pt: 2 samples, 64-wide UNet) take a wider, documented slack.
+# Their yard-stick is the reference run under CPU autocast (the only way the reference SDXL head runs in bf16 at all).  Rounds 3-4
+# explained the 1.1-1.2x ratio by "autocast keeps norms / softmax in fp32"; round 5 TESTED that: re-running the yard-stick with every
+# GroupNorm / LayerNorm / softmax result rounded to bf16 where it is produced gives the SAME errors to four digits (CPU autocast runs
+# those ops in the input dtype already) -- the yard-stick IS like for like.  What remains is the spread of a 2-sample gradient error
+# under re-association (a different split-K factor or kernel family upstream moves it by 5-10 %: 1.11x in round 3, 1.19x in round 4 on
+# `grad_global_projector`), while the same gradients at the real size (2.567 G parameters, tests/test_fullsize_depth_gpu.py) sit at
+# 0.7-0.8x their yard-stick under the plain 1.15 rule.  Those tiny-model checks -- and only those -- take this slack; every measured
+# pair still lands in the parity report with its bound.
 AUTOCAST_YARDSTICK_SLACK = 1.30
 
 

@@ -137,7 +137,85 @@ def test_vicuna7b_full_depth_hidden_states_logits_and_greedy_decode_vs_oracle():
             agree += int(int(o[:VL].argmax()) == int(r[:VL].argmax()))
     assert agree == decided, f"greedy argmax differs from the oracle on {decided - agree} of {decided} decidable steps"
     check_scalar("depth.greedy_decidable_steps_agree", agree, decided)
+    # VERDICT r04 weak #1d: with N(0, 0.02) weights the logits over 32000 tokens are nearly flat, the top-2 margin is seldom above what
+    # a bf16 program resolves and the check above may hold vacuously (`decided` is logged).  The same comparison over the FIRST v
+    # tokens of the vocabulary (a greedy step restricted to v candidates: the margin between the best two of v Gaussians grows as v
+    # shrinks, the bf16 noise does not) must agree on every decidable step too -- and at v = 16 at least half of the steps ARE decidable.
+    counts = {VL: (decided, agree)}
+    for v in (4096, 512, 64, 16):
+        dec_v = agr_v = 0
+        for j in range(NEW):
+            r, y, o = step_ref[j][:v], step_yard[j][:v], ours_steps[j][:v]
+            top2 = r.topk(2).values
+            if float(top2[0] - top2[1]) > 2.0 * float((y - r).abs().max()):
+                dec_v += 1
+                agr_v += int(int(o.argmax()) == int(r.argmax()))
+        counts[v] = (dec_v, agr_v)
+        assert agr_v == dec_v, f"argmax over the first {v} tokens differs from the oracle on {dec_v - agr_v} of {dec_v} decidable steps"
+        check_scalar(f"depth.greedy_decidable_steps_agree.vocab{v}", agr_v, dec_v)
+    print("greedy: vocabulary -> (decidable steps of 16, agreeing):", counts)
+    assert counts[16][0] >= NEW // 2, f"only {counts[16][0]} of {NEW} steps decidable even over 16 candidates"
     del sess, model
+    torch.cuda.empty_cache()
+
+
+def test_vicuna7b_dims_8_layer_backward_gradient_error_growth_vs_oracle():
+    """VERDICT r04 missing #5 / weak #1e ("loss + selected grad-norm parity on step 0"): the deepest
+    oracle-checked BACKWARD was 2 layers.  An 8-layer Vicuna-7B-dims text-only training step (B = 1, S = 1024, fused lm_head + CE):
+    loss, and for EVERY layer the gradients of the packed q|k|v, o_proj, gate|up, down_proj and both norm weights against the fp32
+    oracle's autograd, beside the oracle run in bf16 -- the gradient error as a function of the distance from the loss
+    (modeling_dreamllm.py:599-654,986-1022,1452-1470)."""
+    from dreamllm_amd.factory import VICUNA_7B, build_dreamllm
+    from oracle import llm_ref
+    L, S = 8, 1024
+    model = build_dreamllm(dict(VICUNA_7B, num_hidden_layers=L), device=DEV, seed=17, with_sd=False, with_clip=False).train()
+    g = torch.Generator(device=DEV).manual_seed(23)
+    ids = torch.randint(3, 32000, (1, S), device=DEV, generator=g)
+    labels = ids.clone()
+    labels[:, :7] = -100
+    model.zero_grad(set_to_none=True)
+    out = model(input_ids=ids, labels=labels, return_dict=True)
+    out.loss.backward()
+    full = {k: v.detach().float() for k, v in model.state_dict().items()}
+    cd = dict(hidden_size=4096, intermediate_size=11008, num_hidden_layers=L, num_attention_heads=32, num_key_value_heads=32,
+              rms_norm_eps=model.config.rms_norm_eps, max_position_embeddings=2048, vocab_size=model.config.vocab_size, special_ids={})
+    llm_keys = [k for k in full if k.startswith("model.layers.") or k in ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight")]
+
+    def oracle(dtype):
+        sd = {k: full[k].to(dtype).requires_grad_(True) for k in llm_keys}
+        emb = F.embedding(ids, sd["model.embed_tokens.weight"])
+        hidden = llm_ref.model_forward(emb, sd, cd, attention_mask=None)
+        lm, _ = llm_ref.lm_loss(hidden, sd["lm_head.weight"], labels)
+        lm.backward()
+        return float(lm), {k: v.grad.float() for k, v in sd.items() if v.grad is not None}
+
+    lr_, gr = oracle(torch.float32)
+    lb_, gb = oracle(BF)
+    check_scalar("depth8.bwd.loss", out.loss, lr_, abs(lb_ - lr_))
+    params = dict(model.named_parameters())
+    growth = {}
+    for i in range(L):
+        pre = f"model.layers.{i}."
+        errs = []
+        for n in ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight", "self_attn.o_proj.weight",
+                  "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight", "input_layernorm.weight",
+                  "post_attention_layernorm.weight"):
+            k = pre + n
+            e = check_tensor("depth8.bwd.grad." + k, params[k].grad, gr[k], rel_l2(gb[k], gr[k]))
+            errs.append((e, rel_l2(gb[k], gr[k])))
+        # grad-norm parity of the whole layer (SURVEY 8(d) row 4)
+        ours_n = math.sqrt(sum(float(params[pre + n].grad.float().square().sum()) for n in
+                               ("self_attn.q_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight")))
+        ref_n = math.sqrt(sum(float(gr[pre + n].square().sum()) for n in
+                              ("self_attn.q_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight")))
+        yard_n = math.sqrt(sum(float(gb[pre + n].square().sum()) for n in
+                               ("self_attn.q_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight")))
+        check_scalar(f"depth8.bwd.grad_norm.layer{i}", ours_n, ref_n, abs(yard_n - ref_n), rtol=2e-3)
+        growth[i] = (max(a for a, _ in errs), max(b for _, b in errs))
+    for k in ("model.embed_tokens.weight", "lm_head.weight", "model.norm.weight"):
+        check_tensor("depth8.bwd.grad." + k, params[k].grad, gr[k], rel_l2(gb[k], gr[k]))
+    print("layer -> (max grad err ours, max grad err of the oracle in bf16):", {i: (f"{a:.3e}", f"{b:.3e}") for i, (a, b) in growth.items()})
+    del model
     torch.cuda.empty_cache()
 
 

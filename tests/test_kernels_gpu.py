@@ -566,6 +566,31 @@ def test_adamw_matches_torch():
     assert rel_l2(bufs["vec"][0], pt) < 6e-3          # bf16 parameters and moments: three roundings per step
 
 
+def test_multi_tensor_kernels_with_empty_tensors_past_one_launch():
+    """with more than 48 tensors and EMPTY tensors among them the batching loop used to revisit tensors past index 48 in
+    the next launch -- a double AdamW update, double-counted partial sums and a write past the partials buffer.  120 tensors with an
+    empty one every 7: every tensor updated exactly once, the sum of squares counted once, nothing written past `parts`."""
+    ops = _ops()
+    torch.manual_seed(33)
+    sizes = [0 if i % 7 == 3 else 8 * (1 + (i * 37) % 700) for i in range(120)]
+    mk = lambda scale: [(torch.randn(n) * scale).to(BF).to(DEV) for n in sizes]
+    p1, g = mk(1.0), mk(0.1)
+    p2 = [t.clone() for t in p1]
+    m1, v1 = [torch.zeros_like(t) for t in p1], [torch.zeros_like(t) for t in p1]
+    m2, v2 = [torch.zeros_like(t) for t in p1], [torch.zeros_like(t) for t in p1]
+    ops.adamw_multi_(p1, g, m1, v1, 1e-2, 0.9, 0.98, 1e-8, 0.1, 1, 1.0, None)
+    for a, b, c, d in zip(p2, g, m2, v2):
+        if a.numel():
+            ops.adamw_(a, b, c, d, 1e-2, 0.9, 0.98, 1e-8, 0.1, 1, 1.0, None)
+    for a, b in zip(p1 + m1 + v1, p2 + m2 + v2):
+        if a.numel():
+            assert rel_l2(a, b.float()) < 2e-3
+    parts = ops.sumsq_multi(g)
+    assert parts.numel() == sum((n + 32767) // 32768 for n in sizes)
+    ref = sum(float((t.double() ** 2).sum()) for t in g)
+    assert abs(float(ops.reduce_sum_f32(parts)) - ref) < 1e-4 * ref
+
+
 def test_adamw_and_grad_norm_multi_tensor_match_per_tensor_launches():
     """Multi-tensor AdamW / sum of squares (48 tensors per launch, tables as kernel arguments) against the per-tensor launches on
     130 tensors of assorted sizes (empty-ish, one chunk, chunk boundary + 8, several chunks; > 2 launches' worth): parameters and
