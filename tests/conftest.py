@@ -85,7 +85,7 @@ def check_scalar(name, ours, ref, ref_bf16_abs_err=0.0, rtol=1e-3):
     ours, ref = float(ours), float(ref)
     lim = SLACK * float(ref_bf16_abs_err) + rtol * abs(ref)
     _PARITY_LOG.append(dict(name=name, err=abs(ours - ref) / max(abs(ref), 1e-30), err_ref=float(ref_bf16_abs_err) / max(abs(ref), 1e-30),
-                            bound=lim / max(abs(ref), 1e-30), scalar=True))
+                            bound=lim / max(abs(ref), 1e-30), scalar=True, ours=ours, ref=ref))
     assert abs(ours - ref) <= lim, f"{name}: |{ours:.6f} - {ref:.6f}| = {abs(ours - ref):.3e} > {lim:.3e}"
 
 

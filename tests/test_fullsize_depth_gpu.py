@@ -182,7 +182,7 @@ def test_vicuna7b_dims_8_layer_backward_gradient_error_growth_vs_oracle():
     llm_keys = [k for k in full if k.startswith("model.layers.") or k in ("model.embed_tokens.weight", "model.norm.weight", "lm_head.weight")]
 
     def oracle(dtype):
-        sd = {k: full[k].to(dtype).requires_grad_(True) for k in llm_keys}
+        sd = {k: full[k].detach().to(dtype).clone().requires_grad_(True) for k in llm_keys}   # fresh leaves per run
         emb = F.embedding(ids, sd["model.embed_tokens.weight"])
         hidden = llm_ref.model_forward(emb, sd, cd, attention_mask=None)
         lm, _ = llm_ref.lm_loss(hidden, sd["lm_head.weight"], labels)
