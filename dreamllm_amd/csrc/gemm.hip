@@ -754,6 +754,19 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
             // both waves of a SIMD walk the K tile in phase and the older one wins every arbitration, so without this the younger wave's
             // requests for tile t + 1 queue behind the older wave's MFMAs.  Forward layout (both operands k-contiguous): +0.4 ... +3.7 %
             // sustained (packed gate|up 1319 -> 1355 TF); the dgrad / wgrad layouts lose 0.5-1 % with it and keep equal priorities.
+#if defined(GEMM_PRIO) && GEMM_PRIO == 4   // experiment: the two waves of a SIMD hold priority 1 in opposite halves of the K tile
+            if constexpr (g + 1 == NG / 2 || g + 1 == NG) {
+                const bool first_half_next = (g + 1 == NG);
+                if ((wave >= 4) != first_half_next) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
+#if defined(GEMM_PRIO) && GEMM_PRIO == 5   // experiment: variant 3 in every layout, waves 4-7 only
+            if (wave >= 4) {
+                if constexpr (g + 1 < 4 + NBD) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
 #if !defined(GEMM_PRIO) || GEMM_PRIO == 3
             if constexpr (!defined_gemm_prio_off && AL == A_K && BL == B_K) {
                 if constexpr (g + 1 < 4 + NBD) __builtin_amdgcn_s_setprio(1);

@@ -6,18 +6,18 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffast-math -fno-finite-math-o
 if [ "$1" != "run" ]; then
   mkdir -p $ROOT/tools/bin
   python -m dreamllm_amd.build > /dev/null
-  for k in 0 1 2 3; do
+  for k in ${VARIANTS:-0 1 2 3}; do
     /opt/rocm/bin/hipcc $FLAGS -DGEMM_PRIO=$k -c $ROOT/dreamllm_amd/csrc/gemm.hip -o $ROOT/tools/bin/gemm_prio_$k.o &
   done
   wait
-  for k in 0 1 2 3; do
+  for k in ${VARIANTS:-0 1 2 3}; do
     OBJS=$(ls $ROOT/dreamllm_amd/csrc/build/*.o | grep -v "/gemm.o")
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS $ROOT/tools/bin/gemm_prio_$k.o -o $ROOT/tools/bin/libdllm_prio_$k.so
   done
   ls -la $ROOT/tools/bin/*.so
 else
   for round in 1 2; do
-    for k in 0 1 2 3; do
+    for k in ${VARIANTS:-0 1 2 3}; do
       echo "== round $round GEMM_PRIO=$k"
       DREAMLLM_HIP_LIB=$ROOT/tools/bin/libdllm_prio_$k.so python $ROOT/tools/gemm_sustained.py 0 1.2 2>&1 | grep -v amdgpu.ids
     done
