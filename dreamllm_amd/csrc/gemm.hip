@@ -767,6 +767,13 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
                 else __builtin_amdgcn_s_setprio(0);
             }
 #endif
+#if defined(GEMM_PRIO) && GEMM_PRIO >= 6   // experiments: variant 3 with other extents (6: A-operand requests only, 7: the whole first k step, 8: levels 2 / 0)
+            if constexpr (AL == A_K && BL == B_K) {
+                constexpr int LAST = GEMM_PRIO == 6 ? 4 : (GEMM_PRIO == 7 ? NG / 2 : 4 + NBD);
+                if constexpr (g + 1 < LAST) __builtin_amdgcn_s_setprio(GEMM_PRIO == 8 ? 2 : 1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
 #if !defined(GEMM_PRIO) || GEMM_PRIO == 3
             if constexpr (!defined_gemm_prio_off && AL == A_K && BL == B_K) {
                 if constexpr (g + 1 < 4 + NBD) __builtin_amdgcn_s_setprio(1);
