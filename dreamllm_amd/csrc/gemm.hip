@@ -775,11 +775,9 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
             }
 #endif
 #if !defined(GEMM_PRIO) || GEMM_PRIO == 3
-#if defined(GEMM_PRIO_CONV)   // experiment: the same placement for the implicit-GEMM conv layouts
+            // (the implicit-GEMM conv layouts take it too: B_img 8 denoise loop 43.14 -> 43.32 steps/s in two interleaved rounds,
+            // profiles/r05_denoise_prio_ab.log; on the ring kernel both placements tried there measured equal or slower)
             constexpr bool kPrioLayout = (AL == A_K || AL == A_CONV || AL == A_CONVS) && BL == B_K;
-#else
-            constexpr bool kPrioLayout = AL == A_K && BL == B_K;
-#endif
             if constexpr (!defined_gemm_prio_off && kPrioLayout) {
                 if constexpr (g + 1 < 4 + NBD) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
