@@ -238,9 +238,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
             fragr_issue<false, 0, 0>(fa[0], ab);
         };
         first_reads();
-#if defined(RING_PRIO) && RING_PRIO == 1   // experiment: the younger half of the work-group at static priority 1
-        if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 
         for (int t = 0; t < nt; ++t) {
             // stage t+3 goes into the slot stage t-1 was read from: every wave finished those reads before the last barrier
@@ -250,13 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
             static_for<0, NG>([&](auto gc) {
                 constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
                 if (dma_mode == 0 || dma_mode == 5) {
-#if defined(RING_PRIO) && RING_PRIO == 2   // experiment: the request at priority 1
-                    __builtin_amdgcn_s_setprio(1);
-#endif
                     if (pf) issue_one(kpf, pslot, g);   // one DMA instruction per MFMA group
-#if defined(RING_PRIO) && RING_PRIO == 2
-                    __builtin_amdgcn_s_setprio(0);
-#endif
                 } else if (dma_mode == 1 || (dma_mode == 2 && t == 0)) {   // all four at the start of the tile
                     if constexpr (g == 0) {
                         if (pf) {
