@@ -140,13 +140,16 @@ int dllm_sumpool2_nhwc(const void* in, void* out, int NB, int H, int W, int C, v
  * leading keys and every query is valid), CLIP self-attention and the UNet self/cross attention [ext].
  * q,o: [B,Sq,H,D] views (element strides sb,ss,sh; d contiguous); k,v: [B,Sk,Hkv,D] views sharing one stride set;
  * D in {64,128}; H % Hkv == 0 (GQA, repeat_kv :242-251); seqlens / seqstart int32[B] or NULL; lse fp32 [B,H,Sq] or NULL.
- * `causal`: bit 0 = causal mask; bits 1-2 select the forward kernel per call (0 automatic: the 8-wave software-pipelined
- * 256-query kernel for Sq >= 512, the 4-wave 128-query kernel below; 1 / 2 force one of them -- tests run both everywhere). */
+ * `causal`: bit 0 = causal mask; bits 1-2 select the forward kernel per call: 0 automatic (Sq >= 512: the round-5 "ping-pong"
+ * 256-query kernel of csrc/attn_fwd_pp.hip -- the two waves of a SIMD one segment apart, MFMA 32x32x16, register-resident K / V
+ * fragments -- when one (batch, head) key axis spans < 1 GiB, else the 8-wave pipelined kernel; below 512 the 4-wave 128-query
+ * kernel); 1 / 2 / 3 force the 4-wave / 8-wave pipelined / ping-pong kernel -- the tests run every shape through all three. */
 int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int* seqlens, const int* seqstart, int B,
                   int H, int Hkv, int Sq, int Sk, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
                   int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale, int causal, void* stream);
 /* its autograd: dq/dk/dv (dk,dv share strides; may alias slices of one packed dQKV buffer); delta: fp32 [3,B,H,Sq] workspace
-   (planes delta, -delta, -lse/scale).  Bits 1-2 of `causal` select the kernels as in dllm_attn_fwd. */
+   (planes delta, -delta, -lse/scale).  Bits 1-2 of `causal` select the kernels as in dllm_attn_fwd (1 the 4-wave kernels, 2 and 3
+   the 8-wave pipelined ones: the ping-pong form exists for the forward only). */
 int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* o, const float* lse, float* delta,
                   void* dq, void* dk, void* dv, const int* seqlens, const int* seqstart, int B, int H, int Hkv, int Sq, int Sk, int D,
                   int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
