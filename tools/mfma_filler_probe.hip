@@ -123,6 +123,81 @@ void run_valu(const char* tag, const float* in, float* out, uint64_t* stamps) {
            (double)h[0] / rep / 96 / (NW / 4));
 }
 
+// LDS-read fillers beside MFMAs: LK 0 one ds_read_b128 per MFMA, 1 two ds_read_b64, 2 two ds_read_b64_tr_b16, 3 one ds_read_b64, 4 none
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_;
+template <int LK, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void probe_lds(const float* in, float* out, uint64_t* stamps, int rep) {
+    __shared__ __attribute__((aligned(16))) char lds[NW * 2048];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    f32x16 acc[4];
+    bf16x8 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = in[(lane + r + i) & 255];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            a[i][e] = (__bf16)in[(lane * 3 + e + i) & 255];
+            b[i][e] = (__bf16)in[(lane * 5 + e + i) & 255];
+        }
+    }
+    for (int i = threadIdx.x; i < NW * 512; i += NW * 64) reinterpret_cast<float*>(lds)[i] = in[i & 255];
+    __syncthreads();
+    const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds + wave * 2048;
+    const uint32_t a128 = base + lane * 16, a64 = base + lane * 8;
+    u32x4_ r4[4];
+    u32x2_ r2[8];
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < rep; ++it) {
+        sfor<0, 16>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3], b[i >> 2], acc[i & 3], 0, 0, 0);
+            if constexpr (LK == 0) {
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r4[i & 3]) : "v"(a128), "n"((i & 1) * 1024));
+            } else if constexpr (LK == 1) {
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r2[(2 * i) & 7]) : "v"(a64), "n"((i & 3) * 512));
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r2[(2 * i + 1) & 7]) : "v"(a64), "n"(((i + 1) & 3) * 512));
+            } else if constexpr (LK == 2) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r2[(2 * i) & 7]) : "v"(a64), "n"((i & 3) * 512));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r2[(2 * i + 1) & 7]) : "v"(a64), "n"(((i + 1) & 3) * 512));
+            } else if constexpr (LK == 3) {
+                asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r2[i & 7]) : "v"(a64), "n"((i & 3) * 512));
+            }
+            if constexpr ((i & 3) == 3 && LK != 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (LK == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { asm volatile("" : "+v"(r4[i])); s += __uint_as_float(r4[i][0]); }
+    } else if (LK != 4) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { asm volatile("" : "+v"(r2[i])); s += __uint_as_float(r2[i][0]); }
+    }
+    out[blockIdx.x * NW * 64 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && lane == 0) stamps[wave] = t1 - t0;
+}
+template <int LK, int NW>
+void run_lds(const char* tag, const float* in, float* out, uint64_t* stamps) {
+    const int rep = 2000;
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((probe_lds<LK, NW>), dim3(256), dim3(NW * 64), 0, 0, in, out, stamps, rep);
+    hipDeviceSynchronize();
+    uint64_t h[8];
+    hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
+    printf("%-58s waves/SIMD %d : wave0 %7.1f clk per cluster (%5.1f per MFMA)", tag, NW / 4, (double)h[0] / rep, (double)h[0] / rep / 16);
+    if (NW == 8) printf("   wave4 %7.1f", (double)h[4] / rep);
+    printf("\n");
+}
+
 template <int PAT, int NW, int MODE>  // MODE 0: every wave runs the cluster; 1: waves >= 4 run the VALU stream instead; 2: waves >= 4 idle
 __global__ __launch_bounds__(NW * 64, NW / 4) void probe(const float* in, float* out, uint64_t* stamps, int rep) {
     const int lane = threadIdx.x & 63;
@@ -204,6 +279,14 @@ int main() {
     run<0, 8, 1>("bare MFMAs beside a VALU-only partner (96 VALU / iter)", in, out, stamps);
     run<1, 8, 1>("MFMA + 2 asm v_add beside a VALU-only partner", in, out, stamps);
     run<5, 8, 1>("MFMA + 2 fma + 2 exp beside a VALU-only partner", in, out, stamps);
+    run_lds<4, 4>("MFMA, no LDS read", in, out, stamps);
+    run_lds<0, 4>("MFMA + 1 ds_read_b128 (1 KiB per wave)", in, out, stamps);
+    run_lds<1, 4>("MFMA + 2 ds_read_b64 (1 KiB per wave)", in, out, stamps);
+    run_lds<2, 4>("MFMA + 2 ds_read_b64_tr_b16 (1 KiB per wave)", in, out, stamps);
+    run_lds<3, 4>("MFMA + 1 ds_read_b64 (512 B per wave)", in, out, stamps);
+    run_lds<0, 8>("MFMA + 1 ds_read_b128, both waves", in, out, stamps);
+    run_lds<1, 8>("MFMA + 2 ds_read_b64, both waves", in, out, stamps);
+    run_lds<2, 8>("MFMA + 2 ds_read_b64_tr_b16, both waves", in, out, stamps);
     run_valu<0, 4>("VALU only: v_fma_f32", in, out, stamps);
     run_valu<0, 8>("VALU only: v_fma_f32", in, out, stamps);
     run_valu<0, 16>("VALU only: v_fma_f32", in, out, stamps);
