@@ -16,6 +16,8 @@
 // P = exp(scale*S - LSE) uses the forward's saved log-sum-exp; dS = P * (dP - delta).
 #include "attn_common.h"
 
+__attribute__((visibility("hidden"))) int dllm_launch_attn_bwd_dq_pp(const AttnParams& P, int causal, void* tl_out, hipStream_t stream);
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------ delta
@@ -1058,7 +1060,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv8_kernel(AttnParams P) {
 }
 
 template <int D, bool CAUSAL>
-int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_dkv) {
+int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_dkv, bool pp_dq) {
     constexpr int QT = (D == 128) ? 1 : 2;
     constexpr int KT = (D == 128) ? 1 : 2;
     constexpr int LDS_DQ = 2 * 2 * 64 * D * 2;
@@ -1069,7 +1071,10 @@ int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_
     if (!wide_dq)  // the 8-wave dQ kernel computes delta and publishes the statistic planes itself
         hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, stream, P);
     constexpr int BQ = 4 * QT * 16, BKEYS = 4 * KT * 16;
-    if (wide_dq) {
+    if (wide_dq && pp_dq && D == 128) {  // ping-pong dQ kernel (attn_bwd_pp.hip): computes delta and the statistic planes as well
+        const int rc = dllm_launch_attn_bwd_dq_pp(P, CAUSAL ? 1 : 0, nullptr, stream);
+        if (rc != DLLM_OK) return rc;
+    } else if (wide_dq) {
         dllm_ensure_dyn_lds(&attn_bwd_dq8_kernel<D, CAUSAL>, LDS_DQ, lds3_ok);
         const int nqb8 = (P.Sq + 255) / 256;  // causal: one group per pair of row blocks
                 hipLaunchKernelGGL((attn_bwd_dq8_kernel<D, CAUSAL>), dim3(attn_grid(CAUSAL ? (nqb8 + 1) / 2 : nqb8, P.H, P.B)), dim3(512), LDS_DQ, stream, P);
@@ -1134,9 +1139,29 @@ int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v,
     P.causal = causal;
     // automatic: the 256-row kernels where the row axis they tile is long enough to fill their blocks (UNet cross-attention has
     // Sq = 4096 queries over Sk = 64 dream tokens: wide dQ, 4-wave dK/dV)
-    const bool wq = force >= 2 || (force == 0 && Sq >= 512), wk = force >= 2 || (force == 0 && Sk >= 512);  // 3 = forward-only choice
-    if (D == 128) return causal ? launch_bwd<128, true>(P, s, wq, wk) : launch_bwd<128, false>(P, s, wq, wk);
-    return causal ? launch_bwd<64, true>(P, s, wq, wk) : launch_bwd<64, false>(P, s, wq, wk);
+    const bool wq = force >= 2 || (force == 0 && Sq >= 512), wk = force >= 2 || (force == 0 && Sk >= 512);
+    // 3 / automatic: the ping-pong dQ kernel (D = 128; 32-bit key-axis offsets and 16-byte dQ stores are its preconditions)
+    const bool pp = force != 2 && (int64_t)Sk * k_ss < (1ll << 29) && ((dq_ss | dq_sh | dq_sb) & 7) == 0 && ((uintptr_t)dq & 15) == 0;
+    if (D == 128) return causal ? launch_bwd<128, true>(P, s, wq, wk, pp) : launch_bwd<128, false>(P, s, wq, wk, pp);
+    return causal ? launch_bwd<64, true>(P, s, wq, wk, false) : launch_bwd<64, false>(P, s, wq, wk, false);
 }
+
+#ifdef DLLM_BENCH_MODES
+// benchmark-only: the ping-pong dQ kernel alone (causal, head_dim 128, [B,S,H,D] contiguous operands) with s_memtime stamps of one
+// work-group written to `stamps` (2 x 512 uint64: wave 0, wave 4; two stamps around every barrier of the first pass); stamps == null
+// runs the plain kernel (for timing it alone)
+int dllm_attn_bwd_dq_pp_timeline(const void* dout, const void* q, const void* k, const void* v, const void* o, const float* lse,
+                                 float* delta, void* dq, void* stamps, int B, int H, int Sq, void* stream) {
+    AttnParams P{};
+    const int D = 128;
+    P.q = (const bf16*)q; P.k = (const bf16*)k; P.v = (const bf16*)v; P.o = (bf16*)o; P.dout = (const bf16*)dout; P.dq = (bf16*)dq;
+    P.lse = (float*)lse; P.delta = delta;
+    P.B = B; P.H = H; P.Hkv = H; P.Sq = Sq; P.Sk = Sq;
+    P.q_sb = P.k_sb = P.o_sb = P.dq_sb = (int64_t)Sq * H * D; P.q_ss = P.k_ss = P.o_ss = P.dq_ss = (int64_t)H * D;
+    P.q_sh = P.k_sh = P.o_sh = P.dq_sh = D;
+    P.scale = 0.08838834764f; P.causal = 1;
+    return dllm_launch_attn_bwd_dq_pp(P, 1, stamps, (hipStream_t)stream);
+}
+#endif
 
 }  // extern "C"

@@ -1,5 +1,5 @@
 """Attention forward / backward timings at the bench shape (B16 x S2048 x H32 x D128 causal) and the UNet shapes, per kernel
-variant (ops.ATTN_VARIANT: 1 = 4-wave, 2 = 8-wave pipelined).  Interleaved rounds in one process (guide rule 24)."""
+variant (ops.ATTN_VARIANT: 1 = 4-wave, 2 = 8-wave pipelined, 3 = ping-pong forward / ping-pong dQ).  Interleaved rounds in one process (guide rule 24)."""
 import os
 import sys
 
@@ -40,7 +40,7 @@ for name, B, Sq, Sk, H, D, causal in shapes:
     o, lse = ops.attn_fwd(q, k, v, causal)
     resb = {}
     for rnd in range(2):
-        for var in (1, 2):
+        for var in (1, 2, 3):
             ops.ATTN_VARIANT = var
             resb.setdefault(var, []).append(timed(lambda: ops.attn_bwd(do, q, k, v, o, lse, causal)))
     ops.ATTN_VARIANT = 0
