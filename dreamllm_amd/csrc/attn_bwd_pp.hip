@@ -208,12 +208,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
         const int nblk = kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0;
 #endif
 
-        BP_PHASE(1 + 5 * pass);
+        BP_PHASE(1 + 8 * pass);
         // ---- operands and statistics: this is the first backward kernel, it computes delta and (with the store tail) publishes the
         // statistic planes delta, -delta and -lse / scale for the dK / dV kernels, exactly as attn_bwd_dq8_kernel does
         float nlse2, ndlt;
         {
             request_pass(qblk, nblk);
+            BP_PHASE(2 + 8 * pass);
             const float lse = lse_v;
             float dsum = 0.f;
 #pragma unroll
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
             pin_loaded(nlse2);
             pin_loaded(ndlt);
         }
-        BP_PHASE(2 + 5 * pass);
+        BP_PHASE(3 + 8 * pass);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first tiles landed (this wave's shares); the barrier publishes them
 
         f32x16 dqacc[DBN];
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
         if (CAUSAL && wq0 + QW - 1 + coff < 0) nact = 0;
 
         bp_barrier();
+        BP_PHASE(4 + 8 * pass);
         // row fragments d 0-63 of the next half tile (loop carried): rf[2 i] = K fragment of d step i, rf[2 i + 1] = V fragment
         u32x4 rf[8];
         auto load_rows = [ra0](u32x4 (&dst)[8], auto kbc, auto d0c, uint32_t slotoff) {
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
             static_for_<0, 8>([&rf](auto fc) { asm volatile("" : "+v"(rf[decltype(fc)::value])); });
         }
         if (grpB) bp_barrier();  // group B starts one interval late ...
-        BP_PHASE(3 + 5 * pass);
+        BP_PHASE(5 + 8 * pass);
 
         int slot = 0;
         int j = 0;
@@ -449,8 +451,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
             slot = slot + 1 == PF ? 0 : slot + 1;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        BP_PHASE(4 + 5 * pass);
+        BP_PHASE(6 + 8 * pass);
         if (!grpB) bp_barrier();  // ... and group A waits for it at the end: every wave has passed its last LDS read
+        BP_PHASE(7 + 8 * pass);
         if constexpr (TL) {
             BP_STAMP();
             if (tl_on) {
@@ -469,10 +472,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
         {  // statistic planes of this wave's rows (delta, -delta, -lse / scale) for the dK / dV kernels
             const int qrow = wq0 + lq;
             if (qrow < sq_len && hi == 0) {
-                const float lse = P.lse[stat0 + qrow];
                 P.delta[stat0 + qrow] = -ndlt;
                 P.delta[plane + stat0 + qrow] = ndlt;
-                P.delta[2 * plane + stat0 + qrow] = -lse / P.scale;
+                P.delta[2 * plane + stat0 + qrow] = -P.lse[stat0 + qrow] / P.scale;  // (from the register copy instead: same kernel time)
             }
         }
         // ---- store: lane (q = lq, hi) holds dQ^T[d = 32 db + (r & 3) + 8 (r >> 2) + 4 hi][q]; as the forward's store tail
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
                     if (qrow < SqE) *reinterpret_cast<u32x4*>(orow + db * 32 + m * 16) = u32x4{x0[0], x1[0], x0[1], x1[1]};
                 }
         }
-        BP_PHASE(5 + 5 * pass);
+        BP_PHASE(8 + 8 * pass);
     }  // pass
 #undef BP_STAMP
 #undef BP_PHASE

@@ -35,11 +35,12 @@ for _ in range(3):
     run(ops._p(stamps))
 torch.cuda.synchronize()
 st = stamps.cpu().tolist()
+PH = ["start", "requested", "delta", "landed+barrier", "loop", "loop-end", "last-barrier", "stored"]
 for w, pb in ((0, 1024), (4, 1088)):
-    ph = st[pb:pb + 11]
-    print(f"wave {w} phases (clk from kernel entry): " + "  ".join(
-        f"pass{p}: start {ph[1 + 5 * p] - ph[0]} operands-requested {ph[2 + 5 * p] - ph[0]} loop {ph[3 + 5 * p] - ph[0]} loop-end {ph[4 + 5 * p] - ph[0]} "
-        f"stored {ph[5 + 5 * p] - ph[0]}" for p in (0, 1)))
+    ph = st[pb:pb + 17]
+    for p in (0, 1):
+        t = [ph[1 + 8 * p + i] - ph[0] for i in range(8)]
+        print(f"wave {w} pass {p}: " + "  ".join(f"{n} {x}" for n, x in zip(PH, t)) + "   | steps: " + " ".join(str(t[i + 1] - t[i]) for i in range(7)))
 names = ["C12(0)", "E+C3(0)", "C12(1)", "E+C3(1)"]
 for w, base in ((0, 0), (4, 512)):
     s = [x for x in st[base:base + 512] if x != 0]
