@@ -76,7 +76,8 @@ GEMM_NO_RING |= (1 << 27) if os.environ.get("DREAMLLM_RING_4STAGE", "0") == "1" 
 
 
 # Attention kernel choice handed to dllm_attn_fwd / dllm_attn_bwd in bits 1-2 of `causal` (include/dreamllm_hip.h): 0 automatic,
-# 1 the 4-wave kernels, 2 the 8-wave pipelined 256-row kernels.  Tests run every shape through both.
+# 1 the 4-wave kernels, 2 the 8-wave pipelined 256-row kernels, 3 the ping-pong kernels (forward: csrc/attn_fwd_pp.hip; backward: the
+# dQ kernel of csrc/attn_bwd_pp.hip at head_dim 128, 8-wave dK / dV).  Tests run every shape through all three.
 ATTN_VARIANT = 0
 
 

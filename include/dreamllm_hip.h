@@ -148,8 +148,10 @@ int dllm_attn_fwd(const void* q, const void* k, const void* v, void* o, float* l
                   int H, int Hkv, int Sq, int Sk, int D, int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh,
                   int64_t o_sb, int64_t o_ss, int64_t o_sh, float scale, int causal, void* stream);
 /* its autograd: dq/dk/dv (dk,dv share strides; may alias slices of one packed dQKV buffer); delta: fp32 [3,B,H,Sq] workspace
-   (planes delta, -delta, -lse/scale).  Bits 1-2 of `causal` select the kernels as in dllm_attn_fwd (1 the 4-wave kernels, 2 and 3
-   the 8-wave pipelined ones: the ping-pong form exists for the forward only). */
+   (planes delta, -delta, -lse/scale).  Bits 1-2 of `causal` select the kernels as in dllm_attn_fwd: 1 the 4-wave kernels, 2 the
+   8-wave pipelined ones; 3 and automatic (axes >= 512) additionally take the ping-pong dQ kernel of csrc/attn_bwd_pp.hip at D = 128
+   when the key axis spans < 1 GiB and dq is 16-byte aligned with strides that are multiples of 8 elements (dK / dV stay on the 8-wave
+   kernels, as does D = 64). */
 int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v, const void* o, const float* lse, float* delta,
                   void* dq, void* dk, void* dv, const int* seqlens, const int* seqstart, int B, int H, int Hkv, int Sq, int Sk, int D,
                   int64_t q_sb, int64_t q_ss, int64_t q_sh, int64_t k_sb, int64_t k_ss, int64_t k_sh, int64_t o_sb, int64_t o_ss, int64_t o_sh,
