@@ -530,21 +530,16 @@ class StableDiffusionHead(MultimodalHead):
                 pred = self.unet(x_in, None, emb_static, context_cache=ctx_static, nhwc_io=True, return_dict=False,
                                  time_bias=tb_static)[0]
             ent = cache[key] = dict(graph=graph, x_in=x_in, tb=tb_static, ctx=ctx_static, pred=pred, stream=side)  # (keeps the stream's handle alive)
-        # refresh of the static buffers by KERNELS, not by Tensor.copy_: a same-device contiguous copy_ is a hipMemcpyAsync, which the
-        # runtime executes as a blit with ~50 us of idle queue in front of it (profiles/r05_denoise_launch_table.txt: 82 of them per
-        # 50-step call = 1.5 % of the loop); one multi-tensor launch for the cross-attention K / V, one elementwise launch per step for
-        # the time-bias row
-        dsts = [d for k in ctx_now for d in ent["ctx"][k]]
-        srcs = [s_ for k in ctx_now for s_ in ctx_now[k]]
-        if dsts:
-            torch._foreach_copy_(dsts, srcs)
+        for k, v in ctx_now.items():
+            for dst, src in zip(ent["ctx"][k], v):
+                dst.copy_(src)
         lat = latents.permute(0, 2, 3, 1).contiguous().float()  # NHWC fp32 master copy
         x_in = ent["x_in"]
         x_in.zero_()
         x_in[:B, ..., :4] = lat.to(self.dtype)
         x_in[B:, ..., :4] = lat.to(self.dtype)
         for i, t in enumerate(ts_host):  # host floats: no per-step device read of the schedule
-            torch.mul(tb_table[i], 1, out=ent["tb"])  # (x * 1: bit-exact, keeps the sign of zeros)
+            ent["tb"].copy_(tb_table[i])
             ent["graph"].replay()
             sched.step_cfg_fused_(ent["pred"], t, lat, x_in, guidance_scale)
         return lat.permute(0, 3, 1, 2).contiguous()
