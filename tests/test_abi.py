@@ -22,6 +22,16 @@ def test_library_builds_and_exports_header_symbols():
     assert not missing, missing
 
 
+def test_shipped_library_exports_nothing_but_the_header():
+    """Bench-mode entry points (timelines, ablations, A/B kernels: DLLM_BENCH_MODES builds -> libdreamllm_hip_bench.so) must not leak into
+    the product library: its dynamic `dllm_*` symbols are exactly the header's."""
+    import subprocess
+    from dreamllm_amd import build
+    out = subprocess.run(["nm", "-D", "--defined-only", build.build()], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("dllm_")})
+    assert exported == _header_symbols(), sorted(set(exported) ^ set(_header_symbols()))
+
+
 def test_python_signatures_cover_the_header():
     from dreamllm_amd import _lib
     declared = set(_lib.SIGNATURES) | set(_lib.RESTYPES)
