@@ -64,7 +64,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnParams P) {
     constexpr int DBN = D / 32;
     constexpr int PITCH = D * 2, TILE = BQ * PITCH, SLOT = 2 * TILE;  // a ring slot = Q tile, then dO tile
     constexpr int CPR = D / 8, RPG = 64 / CPR, NDMA = (BQ / RPG) / NW;
-    static_assert(NDMA == 2 && PF == 3, "request schedule and wait counts below");
+    static_assert(NDMA == 2 && PF >= 3, "request schedule and wait counts below");
+    // Tile j + PF - 1 is requested during tile j.  At the end of a tile's second interval the wave's share of tile j + 1 must have landed:
+    // younger than it are PF - 3 whole tiles (4 requests, 5 for a wave that carries a statistics plane) and the first two intervals'
+    // requests of tile j + PF - 1 (2, or 3).
+    constexpr int WAIT_PLAIN = (PF - 3) * 4 + 2, WAIT_STAT = (PF - 3) * 5 + 3;
+    constexpr int AHEAD = PF - 1;
     constexpr int STAT0 = PF * SLOT;  // statistics ring: PF x {64 x -lse/scale, 64 x -delta}
     constexpr int NSTATW = kDK ? 2 : 1;  // waves 0 (and 1) carry one statistics request per tile on top of the two Q pieces
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -155,10 +160,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnParams P) {
         const int qb_end = (sq_len + BQ - 1) / BQ;
         nq = (k0 < sk_len && qb_end > qb_begin) ? (qb_end - qb_begin) : 0;
 
-        // ---- prologue: tiles 0 and 1 of the pass, then this wave's K (and V) rows
+        // ---- prologue: tiles 0 .. PF - 2 of the pass, then this wave's K (and V) rows
         if (nq > 0) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < PF - 1; ++t)
 #pragma unroll
                 for (int part = 0; part < 4; ++part) dma_part(part, t, t);
         }
@@ -198,20 +203,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnParams P) {
         int j = 0;
         for (; j < nidle; ++j) {
             const int pslot = slot == 0 ? PF - 1 : slot - 1;
-            const bool more = j + 2 < nq;
-            if (more) dma_part(0, j + 2, pslot);
+            const bool more = j + AHEAD < nq;
+            if (more) dma_part(0, j + AHEAD, pslot);
             kp_barrier();
             if (more) {
-                dma_part(1, j + 2, pslot);
-                if (wave < NSTATW) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                dma_part(1, j + AHEAD, pslot);
+                if (wave < NSTATW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_STAT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_PLAIN) : "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             kp_barrier();
-            if (more) dma_part(2, j + 2, pslot);
+            if (more) dma_part(2, j + AHEAD, pslot);
             kp_barrier();
-            if (more) dma_part(3, j + 2, pslot);
+            if (more) dma_part(3, j + AHEAD, pslot);
             kp_barrier();
             slot = slot + 1 == PF ? 0 : slot + 1;
         }
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnParams P) {
             const int nslot = slot + 1 == PF ? 0 : slot + 1;
             const int pslot = slot == 0 ? PF - 1 : slot - 1;
             const uint32_t so = (uint32_t)(slot * SLOT), son = (uint32_t)(nslot * SLOT);
-            const bool more = j + 2 < nq;
+            const bool more = j + AHEAD < nq;
             const bool need_mask = (qb0 + BQ > sq_len) || (wk0 + KW > sk_len) || (CAUSAL && (wk0 + KW - 1 > qb0 + coff));
             // query qb0 + c + 4 hi (c = the register's compile-time offset) is dead for key kidx iff it lies below kidx - coff (causal) or
             // past the last query; a key past the end kills its whole column
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnParams P) {
                         });
                     }
                     if constexpr (i == 0) {
-                        if (more) dma_part(2 * kb, j + 2, pslot);
+                        if (more) dma_part(2 * kb, j + AHEAD, pslot);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnParams P) {
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 kp_barrier();
-                if (more) dma_part(2 * kb + 1, j + 2, pslot);
+                if (more) dma_part(2 * kb + 1, j + AHEAD, pslot);
                 // ---------------------------------------------------------------- E: P = exp2(scale log2e S'), dS = P dP'
                 if (need_mask) {
 #pragma unroll
@@ -354,8 +359,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(AttnParams P) {
                 });
                 if constexpr (kb == 0) {  // this wave's share of tile j + 1 landed (younger: the first two intervals' requests of tile j + 2)
                     if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    else if (wave < NSTATW) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                    else if (wave < NSTATW) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_STAT) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_PLAIN) : "memory");
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 static_for_<0, 8>([&rn](auto fc) {
@@ -410,7 +415,10 @@ int launch_dkv_pp(const AttnParams& P, hipStream_t stream) {
 // Called by dllm_attn_bwd (attn_bwd.hip) for D = 128, H == Hkv, long key axes; the caller has checked shapes and alignment.  mode 1 =
 // dV pass, 2 = dK pass.  Must run after the dQ kernel of the same call (reads the statistic planes of the workspace).
 __attribute__((visibility("hidden"))) int dllm_launch_attn_bwd_dkv_pp(const AttnParams& P, int causal, int mode, hipStream_t stream) {
-    if (mode == 1) return causal ? launch_dkv_pp<true, 3, 1>(P, stream) : launch_dkv_pp<false, 3, 1>(P, stream);
-    return causal ? launch_dkv_pp<true, 3, 2>(P, stream) : launch_dkv_pp<false, 3, 2>(P, stream);
+#ifndef KP_PF
+#define KP_PF 3  // 4 (tile j + 3 requested during tile j: 130 KiB of LDS) measured the same: the request -> landed path is not what holds these passes
+#endif
+    if (mode == 1) return causal ? launch_dkv_pp<true, KP_PF, 1>(P, stream) : launch_dkv_pp<false, KP_PF, 1>(P, stream);
+    return causal ? launch_dkv_pp<true, KP_PF, 2>(P, stream) : launch_dkv_pp<false, KP_PF, 2>(P, stream);
 }
 #endif  // DLLM_BENCH_MODES
