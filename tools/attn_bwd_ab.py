@@ -1,8 +1,9 @@
 """Backward of the bench shape per combination of kernels (bench library: bits 2 / 3 of ATTN_VARIANT switch the ping-pong dV / dK pass of
 csrc/attn_bwd_dkv_pp.hip on): DLLM_BENCH_MODES=1 python -m dreamllm_amd.build; python tools/attn_bwd_ab.py"""
 import os, sys
-sys.path.insert(0, "/root/repo")
-os.environ["DREAMLLM_HIP_LIB"] = "/root/repo/dreamllm_amd/libdreamllm_hip_bench.so"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("DREAMLLM_HIP_LIB", os.path.join(ROOT, "dreamllm_amd", "libdreamllm_hip_bench.so"))
 import torch
 from dreamllm_amd import ops
 BF = torch.bfloat16

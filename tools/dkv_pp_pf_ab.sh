@@ -1,12 +1,15 @@
 #!/bin/bash
-cd /root/repo
+# Same-call A/B of two builds of the ping-pong dK / dV passes (csrc/attn_bwd_dkv_pp.hip; here: ring depth 3 vs 4) through
+# tools/attn_bwd_ab.py, then dK / dV of the second build against the 8-wave kernels on five shapes.  Builds first:
+#   DLLM_BENCH_MODES=1 python -m dreamllm_amd.build; FILE=attn_bwd_dkv_pp.hip VARIANTS="pf3:-DKP_PF=3 pf4:-DKP_PF=4" tools/dq_pp_ab.sh
+cd "$(dirname "$0")/.."
+ROOT=$PWD
 for lib in tools/bin/libdqab_pf3.so tools/bin/libdqab_pf4.so; do
-  sed "s|/root/repo/dreamllm_amd/libdreamllm_hip_bench.so|$PWD/$lib|" tools/attn_bwd_ab.py > /tmp/ab_$$.py
-  python /tmp/ab_$$.py 2>&1 | grep " ms" | sed "s|^|$(basename $lib .so) |"
+  DREAMLLM_HIP_LIB=$PWD/$lib python tools/attn_bwd_ab.py 2>&1 | grep " ms" | sed "s|^|$(basename $lib .so) |"
 done
-DREAMLLM_HIP_LIB=$PWD/tools/bin/libdqab_pf4.so python - <<'PY'
+DLLM_ROOT=$ROOT DREAMLLM_HIP_LIB=$PWD/tools/bin/libdqab_pf4.so python - <<'PY'
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.environ.get("DLLM_ROOT", "."))
 import torch
 from dreamllm_amd import ops
 BF = torch.bfloat16
