@@ -54,7 +54,49 @@ def parse():
     ap.add_argument("--ragged-steps", type=int, default=3)
     ap.add_argument("--sharded-grad", action="store_true",
                     help="N>1: reduce-scatter + sharded AdamW + all-gather (distributed.ShardedGradAdamW) instead of DDP all-reduce")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend; anything but nccl (= RCCL) is accepted only together with --launch-check")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="launcher dry run: form the N-rank process group, all-reduce a one per rank, print one JSON line, exit "
+                         "(no GPU work; with --backend gloo it runs on CPU: tests/test_distributed_cpu.py)")
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: re-exec this command line under
+    torch.distributed.run (one rank per GPU, 127.0.0.1, a free port) -- the reference's launcher is torchrun with 8 ranks per
+    node (scripts/train/dreamllm/run_stage2.sh:1).  Rank 0's JSON line is the only stdout of the ranks, so it passes through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def launch_check(a, rank, world):
+    """The part of main() that decides whether an N-rank run is what it claims to be, without any GPU work."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(a.backend, init_method="env://")
+    ranks = 1
+    if a.gpus > 1:
+        if not dist.is_initialized() or dist.get_backend() != a.backend or dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: needs {a.gpus} ranks on backend {a.backend}")
+        ones = torch.ones(1, device=torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0))) if a.backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        ranks = int(ones.item())
+        if ranks != a.gpus:
+            raise SystemExit(f"all-reduce saw {ranks} ranks, expected {a.gpus}")
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": a.gpus, "ranks": ranks, "backend": a.backend if world > 1 else None}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def _median3(fn, reps=3):
@@ -162,11 +204,17 @@ def cpu_baseline(seq_len, budget_s=60.0):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)   # does not return
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.launch_check:
+        return launch_check(a, rank, world)
+    if a.backend != "nccl":
+        raise SystemExit("bench.py measures on RCCL only (--backend gloo is for --launch-check)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     torch.cuda.set_device(local)
@@ -356,8 +404,8 @@ def main():
     # S ~ U{S/2 .. S} per document, right-padded to S, `seqlens` passed: the varlen path of modeling_dreamllm.py:521-545 (per-row spans in
     # the attention kernels, loss on the labelled rows).  Same model / optimizer state; 1 warm-up + `--ragged-steps` timed steps.
     ragged = None
-    if not a.no_train and not a.no_ragged and not tiny:
-        try:
+    if not a.no_train and not a.no_ragged and not tiny and world == 1:   # N = 1 only: a rank that fails alone inside this try
+        try:                                                                  # would leave the others in a collective
             rb = make_interleaved_batch(a.batch, a.seq_len, a.images_per_sample, seed=4321 + rank, device=dev, ragged=True)
             lens = rb["attention_mask"].sum(1).tolist()
             labr = rb["labels"]

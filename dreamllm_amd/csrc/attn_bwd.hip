@@ -17,9 +17,6 @@
 #include "attn_common.h"
 
 __attribute__((visibility("hidden"))) int dllm_launch_attn_bwd_dq_pp(const AttnParams& P, int causal, void* tl_out, hipStream_t stream);
-#ifdef DLLM_BENCH_MODES
-__attribute__((visibility("hidden"))) int dllm_launch_attn_bwd_dkv_pp(const AttnParams& P, int causal, int mode, hipStream_t stream);
-#endif
 
 namespace {
 
@@ -1063,7 +1060,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv8_kernel(AttnParams P) {
 }
 
 template <int D, bool CAUSAL>
-int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_dkv, bool pp_dq, int pp_dkv) {
+int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_dkv, bool pp_dq) {
     constexpr int QT = (D == 128) ? 1 : 2;
     constexpr int KT = (D == 128) ? 1 : 2;
     constexpr int LDS_DQ = 2 * 2 * 64 * D * 2;
@@ -1093,20 +1090,8 @@ int launch_bwd(const AttnParams& P, hipStream_t stream, bool wide_dq, bool wide_
         if constexpr (D == 128) {
             dllm_ensure_dyn_lds(&attn_bwd_dkv8_kernel<D, CAUSAL, 1>, LDS_DKV8, lds4_ok);
             dllm_ensure_dyn_lds(&attn_bwd_dkv8_kernel<D, CAUSAL, 2>, LDS_DKV8, lds5_ok);
-#ifdef DLLM_BENCH_MODES  // bit 0 / 1 of pp_dkv: the ping-pong dV / dK pass (A/B only)
-            if (pp_dkv & 2) {
-                const int rc = dllm_launch_attn_bwd_dkv_pp(P, CAUSAL ? 1 : 0, 2, stream);
-                if (rc != DLLM_OK) return rc;
-            } else
-#endif
-                hipLaunchKernelGGL((attn_bwd_dkv8_kernel<D, CAUSAL, 2>), grid8, dim3(512), LDS_DKV8, stream, P);
-#ifdef DLLM_BENCH_MODES
-            if (pp_dkv & 1) {
-                const int rc = dllm_launch_attn_bwd_dkv_pp(P, CAUSAL ? 1 : 0, 1, stream);
-                if (rc != DLLM_OK) return rc;
-            } else
-#endif
-                hipLaunchKernelGGL((attn_bwd_dkv8_kernel<D, CAUSAL, 1>), grid8, dim3(512), LDS_DKV8, stream, P);
+            hipLaunchKernelGGL((attn_bwd_dkv8_kernel<D, CAUSAL, 2>), grid8, dim3(512), LDS_DKV8, stream, P);
+            hipLaunchKernelGGL((attn_bwd_dkv8_kernel<D, CAUSAL, 1>), grid8, dim3(512), LDS_DKV8, stream, P);
         } else {
             dllm_ensure_dyn_lds(&attn_bwd_dkv8_kernel<D, CAUSAL, 0>, LDS_DKV8, lds4_ok);
             hipLaunchKernelGGL((attn_bwd_dkv8_kernel<D, CAUSAL, 0>), grid8, dim3(512), LDS_DKV8, stream, P);
@@ -1148,25 +1133,21 @@ int dllm_attn_bwd(const void* dout, const void* q, const void* k, const void* v,
     P.o_sb = o_sb; P.o_ss = o_ss; P.o_sh = o_sh; P.scale = scale; P.causal = causal;
     P.dq_sb = dq_sb; P.dq_ss = dq_ss; P.dq_sh = dq_sh; P.dk_sb = dk_sb; P.dk_ss = dk_ss; P.dk_sh = dk_sh;
     hipStream_t s = (hipStream_t)stream;
-    // kernel choice as in dllm_attn_fwd: bits 1-2 of `causal` force the 4-wave (1) or the 8-wave pipelined (2) kernels
-    const int force = causal >> 1;
+    // kernel choice as in dllm_attn_fwd: bits 1-2 of `causal` force the 4-wave (1) or the 8-wave pipelined (2) kernels; higher bits
+    // are not part of the ABI and are rejected
+    if (causal & ~7) return DLLM_ERR_SHAPE;
+    const int force = (causal >> 1) & 3;
     causal &= 1;
     P.causal = causal;
     // automatic: the 256-row kernels where the row axis they tile is long enough to fill their blocks (UNet cross-attention has
     // Sq = 4096 queries over Sk = 64 dream tokens: wide dQ, 4-wave dK/dV)
-    const bool wq = force >= 2 || (force == 0 && Sq >= 512), wk = force >= 2 || (force == 0 && Sk >= 512);
+    const bool wq = force >= 2 || (force == 0 && Sq >= 512), wk = force >= 2 || (force == 0 && Sk >= 512);  // force is 0..3
     // 3 / automatic: the ping-pong dQ kernel (D = 128; 32-bit key-axis offsets and 16-byte dQ stores are its preconditions)
     const bool pp = force != 2 && (int64_t)Sk * k_ss < (1ll << 29) && ((dq_ss | dq_sh | dq_sb) & 7) == 0 && ((uintptr_t)dq & 15) == 0;
-    // The dK / dV passes in the same form (attn_bwd_dkv_pp.hip) measured 0.05 / 0.07 ms SLOWER than the 8-wave kernels
-    // (profiles/r05_attn_bwd_pp_history.md): they exist in DLLM_BENCH_MODES builds only, switched on per call by bits 3 (dV) / 4 (dK) of `causal`.
-    int ppkv = 0;
-#ifdef DLLM_BENCH_MODES
-    if (force != 2 && H == Hkv && (int64_t)Sq * q_ss < (1ll << 29) && (int64_t)Sq * o_ss < (1ll << 29) && ((dk_ss | dk_sh | dk_sb) & 7) == 0 &&
-        (((uintptr_t)dv | (uintptr_t)dk) & 15) == 0)
-        ppkv = (force >> 2) & 3;
-#endif
-    if (D == 128) return causal ? launch_bwd<128, true>(P, s, wq, wk, pp, ppkv) : launch_bwd<128, false>(P, s, wq, wk, pp, ppkv);
-    return causal ? launch_bwd<64, true>(P, s, wq, wk, false, 0) : launch_bwd<64, false>(P, s, wq, wk, false, 0);
+    // (The dK / dV passes in the same form measured 0.05 / 0.07 ms SLOWER than the 8-wave kernels, profiles/r05_attn_bwd_pp_history.md;
+    // that kernel file is kept as profiles/patches/r05_attn_bwd_dkv_pp.hip, outside the library.)
+    if (D == 128) return causal ? launch_bwd<128, true>(P, s, wq, wk, pp) : launch_bwd<128, false>(P, s, wq, wk, pp);
+    return causal ? launch_bwd<64, true>(P, s, wq, wk, false) : launch_bwd<64, false>(P, s, wq, wk, false);
 }
 
 #ifdef DLLM_BENCH_MODES

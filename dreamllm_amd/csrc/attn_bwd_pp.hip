@@ -32,18 +32,14 @@ __device__ __forceinline__ void bp_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ int bp_swz(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
-#ifdef BP_NO_LAUNDER
-#define BP_LAUNDER(x)
-#else
 #define BP_LAUNDER(x) asm volatile("" : "+v"(x))
-#endif
 
 constexpr unsigned kBpTlBlock = 1024;
 
 // TL (bench library only): lane 0 of waves 0 and 4 of work-group kBpTlBlock stamps s_memtime at both sides of every barrier of the
 // first pass into LDS behind the rings; the stamps go to tl_out ([2][512] words: wave 0, wave 4; then the pass phases at word 1024).
-// Build-time experiments (tools/dq_pp_ab.sh; results in profiles/r05_attn_bwd_pp_history.md): BP_NO_LAUNDER, BP_STAGGER=<clk>,
-// BP_ABL_NOTR / BP_ABL_NOC3 / BP_ABL_HALFLOOP (wrong results by design).
+// (The round-5 build-time experiments -- no laundering, staggered first round, the three wrong-result ablations; results in
+// profiles/r05_attn_bwd_pp_history.md -- live in profiles/patches/r05_attn_bwd_pp_experiments.patch, not in this file.)
 template <int D, bool CAUSAL, int PF, bool TL = false>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, uint64_t* tl_out) {
     static_assert(D == 128, "the d = 64 shapes stay on attn_bwd_dq8_kernel");
@@ -89,14 +85,6 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
     const int nitems = CAUSAL ? (nqb + 1) / 2 : nqb;
     const AttnBlock bm = attn_block_map<false>(nitems, P.H, P.B);
     if (!bm.valid) return;
-#ifdef BP_STAGGER
-    // first-round work-groups (one per CU) start staggered: equal-length work-groups otherwise keep all CUs in lockstep -- every CU in
-    // its operand prologue (HBM bound, no MFMA) at the same time, then every CU in its loop (MFMA bound, HBM idle)
-    if (blockIdx.x < 256u * 8u / 8u) {
-        const int lvl = (blockIdx.x >> 3) & 31;
-        for (int i = 0; i < lvl * (BP_STAGGER / 64); i += 16) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
     const int b = bm.b, h = bm.h;
     const int hk = h / (P.H / P.Hkv);
     const AttnSpan sp = attn_span(P, b);
@@ -202,11 +190,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
         }
         int kv_end = sk_len;
         if (CAUSAL) kv_end = min(sk_len, q0 + BQ + coff);
-#ifdef BP_ABL_HALFLOOP  // bench experiment (wrong results): half the key tiles -- splits the kernel time into loop and fixed cost
-        const int nblk = (kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0) / 2;
-#else
         const int nblk = kv_end > 0 ? (kv_end + BKV - 1) / BKV : 0;
-#endif
 
         BP_PHASE(1 + 8 * pass);
         // ---- operands and statistics: this is the first backward kernel, it computes delta and (with the store tail) publishes the
@@ -331,14 +315,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
                             constexpr int f = decltype(fc)::value;
                             constexpr int ks = 2 * kb + (f >> 2), db = f & 3;
                             const uint32_t a = kt ^ (uint32_t)(db << 6);
-#ifdef BP_ABL_NOTR  // bench experiment (wrong results): no transposed reads -- how much of the tile time is LDS bandwidth
-                            asm volatile("v_mov_b32 %0, %1" : "=v"(tlo[f][0]) : "v"(a));
-                            tlo[f][1] = tlo[f][0];
-                            thi[f] = tlo[f];
-#else
                             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(tlo[f]) : "v"(a), "n"(ks * 16 * PITCH));
                             asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(thi[f]) : "v"(a ^ 32u), "n"(ks * 16 * PITCH + 8 * PITCH));
-#endif
                         });
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -403,11 +381,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dq_pp_kernel(AttnParams P, ui
                     constexpr int jj = f >> 2, db = f & 3;
                     const bf16x8 a = join2(tlo[f], thi[f]);
                     const bf16x8 bb = __builtin_bit_cast(bf16x8, u32x4{dsb[jj][0], dsb[jj][1], dsb[jj][2], dsb[jj][3]});
-#ifndef BP_ABL_NOC3
                     dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, dqacc[db], 0, 0, 0);
-#else
-                    asm volatile("" ::"v"(a), "v"(bb));
-#endif
                     if constexpr (f < 4) {  // row fragments d 0-63 of the next half tile, two per step
                         uint32_t ra = ra0 + (kb == 0 ? so : son);
                         BP_LAUNDER(ra);

@@ -211,7 +211,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_pp_kernel(AttnParams P) {
     // first tiles of a pass (K / V tiles 0 .. PF - 2 of the head) and this wave's query rows (B operand of S^T: lane = query lq, d = 16 ds + 8 hi ..)
     bf16x8 qf[DSN];
     auto request_pass = [&](int qblk_, int nblk_) {
-        for (int i = 0; i + 1 < PF; ++i) {
+        // a pass without a visible key (causal Sq > Sk: the first query blocks; an empty key axis) requests nothing -- dma_one's
+        // clamp min(t, nblk_ - 1) would otherwise address the tile in front of the key base
+        for (int i = 0; nblk_ > 0 && i + 1 < PF; ++i) {
 #pragma unroll
             for (int u = 0; u < NDMA; ++u) dma_one(kbase, koff, Ksm, i, nblk_, i, u);
 #pragma unroll

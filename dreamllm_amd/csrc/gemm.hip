@@ -603,11 +603,6 @@ __device__ __forceinline__ void glds_conv_one(const bf16* x, const ConvGeom& g, 
 // BN_ = 256: 2 x 4 waves of 128 x 64; BN_ = 128 (k-contiguous B only): 4 x 2 waves of 64 x 64 -- a 256 x 128 block tile for narrow
 // outputs (the 320-channel UNet layers are 3 x 128 = 83 % full instead of 2 x 256 = 62 %), same wave-level stream.
 //
-#if defined(GEMM_PRIO) && GEMM_PRIO != 3
-constexpr bool defined_gemm_prio_off = true;   // tools/gemm_prio_ab.sh variants 0-2: the shipped placement is switched off
-#else
-constexpr bool defined_gemm_prio_off = false;
-#endif
 // pipe_tile: the K loop of ONE output tile over the K tiles [kt0, kt1) (kt1 > kt0), accumulating into `acc`.  The whole-tile
 // kernel calls it with [0, K / 64); the stream-K tail kernel with a slice of a tile's K loop.
 template <int BN_>
@@ -702,9 +697,6 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     first_reads();
-#if defined(GEMM_PRIO) && GEMM_PRIO == 1   // experiment (tools/gemm_prio_ab.sh): the younger half of the work-group at static priority 1
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
 
     for (int t = kt0; t < kt1; ++t) {
         // tile t+1 goes into the buffer tile t-1 was read from: every wave finished those reads before the last barrier
@@ -741,48 +733,20 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
             }
             if constexpr (i == 0) static_for<0, 4>([&](auto j) { fragr_touch(fb[kk][decltype(j)::value]); });
             const bf16x8 va = fragr_value(fa[g & 1]);
-#if defined(GEMM_PRIO) && GEMM_PRIO == 2   // experiment: priority 1 while a wave issues its MFMA group, 0 while it issues DMA / LDS requests
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
-#if defined(GEMM_PRIO) && GEMM_PRIO == 2
-            __builtin_amdgcn_s_setprio(0);
-#endif
             // Round 5 (profiles/r05_gemm_prio_ab.log): the groups that carry the tile's LDS-DMA requests run at priority 1, the rest at 0 --
             // both waves of a SIMD walk the K tile in phase and the older one wins every arbitration, so without this the younger wave's
             // requests for tile t + 1 queue behind the older wave's MFMAs.  Forward layout (both operands k-contiguous): +0.4 ... +3.7 %
             // sustained (packed gate|up 1319 -> 1355 TF); the dgrad / wgrad layouts lose 0.5-1 % with it and keep equal priorities.
-#if defined(GEMM_PRIO) && GEMM_PRIO == 4   // experiment: the two waves of a SIMD hold priority 1 in opposite halves of the K tile
-            if constexpr (g + 1 == NG / 2 || g + 1 == NG) {
-                const bool first_half_next = (g + 1 == NG);
-                if ((wave >= 4) != first_half_next) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-            }
-#endif
-#if defined(GEMM_PRIO) && GEMM_PRIO == 5   // experiment: variant 3 in every layout, waves 4-7 only
-            if (wave >= 4) {
-                if constexpr (g + 1 < 4 + NBD) __builtin_amdgcn_s_setprio(1);
-                else __builtin_amdgcn_s_setprio(0);
-            }
-#endif
-#if defined(GEMM_PRIO) && GEMM_PRIO >= 6   // experiments: variant 3 with other extents (6: A-operand requests only, 7: the whole first k step, 8: levels 2 / 0)
-            if constexpr (AL == A_K && BL == B_K) {
-                constexpr int LAST = GEMM_PRIO == 6 ? 4 : (GEMM_PRIO == 7 ? NG / 2 : 4 + NBD);
-                if constexpr (g + 1 < LAST) __builtin_amdgcn_s_setprio(GEMM_PRIO == 8 ? 2 : 1);
-                else __builtin_amdgcn_s_setprio(0);
-            }
-#endif
-#if !defined(GEMM_PRIO) || GEMM_PRIO == 3
             // (the implicit-GEMM conv layouts take it too: B_img 8 denoise loop 43.14 -> 43.32 steps/s in two interleaved rounds,
             // profiles/r05_denoise_prio_ab.log; on the ring kernel both placements tried there measured equal or slower)
             constexpr bool kPrioLayout = (AL == A_K || AL == A_CONV || AL == A_CONVS) && BL == B_K;
-            if constexpr (!defined_gemm_prio_off && kPrioLayout) {
+            if constexpr (kPrioLayout) {   // (the seven other placements measured: profiles/patches/r05_gemm_prio_variants.patch)
                 if constexpr (g + 1 < 4 + NBD) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
             }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         });
     }

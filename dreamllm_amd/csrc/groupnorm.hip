@@ -15,6 +15,17 @@ namespace {
 
 // grid (chunks, N); block = CV * R threads (CV = C/8 channel vectors, R rows in flight); x viewed [N][HW][C]
 // MODE 0: accumulate (x, x^2); MODE 1 (backward): accumulate (dxhat, dxhat*xhat) with xhat from ab_mean/rstd.
+// Pivot of the shifted sums (x - pivot) of one (image, group) slice: the MEDIAN of three of its elements (first pixel / first channel,
+// middle pixel / middle channel, last pixel / last channel).  Any value near the slice's mean removes the E[x^2] - mean^2 cancellation
+// of a slice with |mean| >> std; a single element as the pivot re-introduces it when that element is an outlier (|pivot - mean| >> std,
+// ADVICE r05) -- the median of three ignores one outlier.  Every block / thread of a slice computes the same value.
+__device__ __forceinline__ float gn_pivot(const bf16* __restrict__ x, int64_t img_off, int HW, int C, int c0, int cpg) {
+    const float a = (float)x[img_off + c0];
+    const float b = (float)x[img_off + (int64_t)(HW >> 1) * C + c0 + (cpg >> 1)];
+    const float c = (float)x[img_off + (int64_t)(HW - 1) * C + c0 + cpg - 1];
+    return __builtin_amdgcn_fmed3f(a, b, c);
+}
+
 template <int MODE>
 __global__ void gn_partial_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy, const float* __restrict__ mean,
                                   const float* __restrict__ rstd, const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
@@ -28,13 +39,13 @@ __global__ void gn_partial_kernel(const bf16* __restrict__ x, const bf16* __rest
     float s1[8], s2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
-    // MODE 0: sums of (x - pivot), pivot = the (image, group)'s first element: with E[x^2] - mean^2 on raw values a group whose mean is
+    // MODE 0: sums of (x - pivot), pivot = gn_pivot of the (image, group): with E[x^2] - mean^2 on raw values a group whose mean is
     // 100 x its standard deviation (real SD activations get there) loses four digits of the variance in fp32
     float pv[8];
     if (MODE == 0) {
         const int cpg = C / G;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pv[e] = (float)x[(int64_t)n * HW * C + ((cv * 8 + e) / cpg) * cpg];
+        for (int e = 0; e < 8; ++e) pv[e] = gn_pivot(x, (int64_t)n * HW * C, HW, C, ((cv * 8 + e) / cpg) * cpg, cpg);
     }
     float mu[8], rs[8], ga[8], be[8];
     if (MODE == 1) {
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
                                                          int C, int G, float eps, const bf16* __restrict__ x) {
     const int n = blockIdx.x / G, g = blockIdx.x % G;
     const int cpg = C / G;
-    const float pivot = (MODE == 0) ? (float)x[(int64_t)n * HW * C + g * cpg] : 0.f;  // as gn_partial_kernel<0>
+    const float pivot = (MODE == 0) ? gn_pivot(x, (int64_t)n * HW * C, HW, C, g * cpg, cpg) : 0.f;  // as gn_partial_kernel<0>
     float s1 = 0.f, s2 = 0.f;
     const int items = nchunks * cpg;
     for (int i = threadIdx.x; i < items; i += 64) {
@@ -180,8 +191,8 @@ __global__ __launch_bounds__(1024) void gn_small_kernel(const bf16* __restrict__
     const bool live = r < R;
     const int64_t base = (int64_t)n * HW * C + g * cpg + 2 * j;
     const int64_t stride = (int64_t)R * C;
-    // sums of (x - pivot), pivot = the slice's first element (see gn_partial_kernel): no cancellation when |mean| >> std
-    const float pivot = (float)x[(int64_t)n * HW * C + g * cpg];
+    // sums of (x - pivot), pivot = gn_pivot of the slice (see gn_partial_kernel): no cancellation when |mean| >> std
+    const float pivot = gn_pivot(x, (int64_t)n * HW * C, HW, C, g * cpg, cpg);
     float s1 = 0.f, s2 = 0.f;
     if (live) {
         const bf16* px = x + base + (int64_t)r * C;
@@ -260,7 +271,7 @@ __global__ __launch_bounds__(1024) void gn_small_split_kernel(const bf16* __rest
     const int64_t base = (int64_t)n * HW * C + g * cpg + 2 * j;
     const int64_t stride = (int64_t)R * C;
     unsigned* slot = sync + (int64_t)grp * 32;
-    const float pivot = (float)x[(int64_t)n * HW * C + g * cpg];  // the same pivot in all S blocks of the slice (gn_small_kernel)
+    const float pivot = gn_pivot(x, (int64_t)n * HW * C, HW, C, g * cpg, cpg);  // the same pivot in all S blocks of the slice (gn_small_kernel)
     unsigned f0 = 0;
     if (threadIdx.x == 0) {
         f0 = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -392,6 +392,82 @@ def test_attn_fwd(B, H, Hkv, Sq, Sk, D, causal, attn_variant):
     assert rel_l2(lse, lref) < 1e-4
 
 
+@pytest.mark.parametrize("B,H,Hkv,Sq,Sk,D", [
+    (1, 2, 2, 1024, 512, 128),   # the first two 256-row query blocks have no visible key at all
+    (2, 3, 3, 700, 130, 64),
+    (1, 2, 1, 300, 40, 128),
+])
+def test_attn_causal_more_queries_than_keys(B, H, Hkv, Sq, Sk, D, attn_variant):
+    """Causal with Sq > Sk (bottom-right aligned, coff = Sk - Sq < 0): query rows in front of the first key see nothing and are
+    written as zeros (lse 0, zero gradients); the other rows match the fp32 oracle -- forward and backward."""
+    ops = _ops()
+    torch.manual_seed(Sq + 3 * Sk + D)
+    q, k, v, do = rnd(B, Sq, H, D), rnd(B, Sk, Hkv, D), rnd(B, Sk, Hkv, D), rnd(B, Sq, H, D)
+    dead = Sq - Sk   # rows [0, dead) have no visible key
+    qr, kr, vr = (x.float().requires_grad_(True) for x in (q, k, v))
+    oref, lref = attn_ref(qr[:, dead:], kr, vr, True)   # the live rows form an ordinary causal Sk x Sk problem
+    oref.backward(do[:, dead:].float())
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse = ops.attn_fwd(qd, kd, vd, True)
+    assert torch.count_nonzero(o[:, :dead]) == 0 and torch.count_nonzero(lse[:, :, :dead]) == 0
+    assert rel_l2(o[:, dead:], oref) < 6e-3
+    assert rel_l2(lse[:, :, dead:], lref) < 3e-4   # short key axes: small |lse|, the absolute error of exp2 / log is unchanged
+    dq, dk, dv = ops.attn_bwd(do.to(DEV), qd, kd, vd, o, lse, True)
+    assert torch.count_nonzero(dq[:, :dead]) == 0
+    assert rel_l2(dq[:, dead:], qr.grad[:, dead:]) < 1.5e-2
+    assert rel_l2(dk, kr.grad) < 1.5e-2
+    assert rel_l2(dv, vr.grad) < 1.5e-2
+
+
+@pytest.mark.parametrize("Sq", [64, 600])
+def test_attn_fwd_empty_key_axis(Sq, attn_variant):
+    """No visible key for anybody: Sk == 0, and a KV cache whose first-valid-key index lies at the end of the key axis."""
+    ops = _ops()
+    B, H, D = 2, 2, 128
+    q = rnd(B, Sq, H, D, seed=3).to(DEV)
+    k0 = torch.empty(B, 0, H, D, dtype=BF, device=DEV)
+    for causal in (False, True):
+        o, lse = ops.attn_fwd(q, k0, k0, causal)
+        assert torch.count_nonzero(o) == 0 and torch.count_nonzero(lse) == 0
+    Sk = Sq + 64
+    k, v = rnd(B, Sk, H, D).to(DEV), rnd(B, Sk, H, D).to(DEV)
+    start = torch.tensor([Sk, 0], dtype=torch.int32, device=DEV)   # row 0: every key is padding; row 1: ordinary
+    o, lse = ops.attn_fwd(q, k, v, True, seqstart=start)
+    assert torch.count_nonzero(o[0]) == 0 and torch.count_nonzero(lse[0]) == 0
+    oref, lref = attn_ref(q[1:].cpu(), k[1:].cpu(), v[1:].cpu(), True)
+    assert rel_l2(o[1:], oref) < 6e-3 and rel_l2(lse[1:], lref) < 1e-4
+
+
+def test_attn_huge_key_stride_takes_the_64bit_kernels():
+    """The ping-pong kernels address a (batch, head) key axis with 32-bit byte offsets: Sk * k_ss must stay below 2^29 elements.
+    A strided view beyond that (every 2^19-th token row of a large buffer) must take the 8-wave kernels, automatically AND when
+    the ping-pong family is forced, with unchanged results."""
+    ops = _ops()
+    B, S, H, D = 1, 1024, 1, 128
+    pitch = 1 << 19                               # elements between consecutive tokens: S * pitch = 2^29
+    big = torch.zeros(S * pitch + H * D, dtype=BF, device=DEV)   # 1 GiB
+    torch.manual_seed(5)
+    q, do = rnd(B, S, H, D).to(DEV), rnd(B, S, H, D).to(DEV)
+    kc, vc = rnd(B, S, H, D).to(DEV), rnd(B, S, H, D).to(DEV)
+    k = torch.as_strided(big, (B, S, H, D), (0, pitch, D, 1))
+    k.copy_(kc)
+    vbig = torch.zeros_like(big)
+    v = torch.as_strided(vbig, (B, S, H, D), (0, pitch, D, 1))
+    v.copy_(vc)
+    ops.ATTN_VARIANT = 2
+    try:
+        o2, l2 = ops.attn_fwd(q, kc, vc, True)
+        g2 = ops.attn_bwd(do, q, kc, vc, o2, l2, True)
+        for var in (0, 3):
+            ops.ATTN_VARIANT = var
+            o, lse = ops.attn_fwd(q, k, v, True)
+            assert torch.equal(o, o2) and torch.equal(lse, l2), var
+            dq, dk, dv = ops.attn_bwd(do, q, k, v, o, lse, True)
+            assert torch.equal(dq, g2[0]) and torch.equal(dk, g2[1]) and torch.equal(dv, g2[2]), var
+    finally:
+        ops.ATTN_VARIANT = 0
+
+
 def test_attn_fwd_strided_qkv_and_padding(attn_variant):
     """q/k/v as strided views of one fused [B,S,3,H,D] buffer; right padding handled through seqlens."""
     ops = _ops()
