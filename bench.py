@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the short config-2 / config-5 legs (N = 1 only)")
     ap.add_argument("--no-ragged", action="store_true", help="skip the secondary ragged (varlen) training leg (S ~ U{S/2..S}, seqlens passed)")
     ap.add_argument("--ragged-steps", type=int, default=3)
+    ap.add_argument("--no-grad-ckpt-leg", action="store_true", help="skip the secondary gradient-checkpointing leg (2 steps)")
     ap.add_argument("--sharded-grad", action="store_true",
                     help="N>1: reduce-scatter + sharded AdamW + all-gather (distributed.ShardedGradAdamW) instead of DDP all-reduce")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -447,6 +448,31 @@ def main():
         except Exception as ex:  # secondary leg: never lose the headline line
             ragged = {"error": repr(ex)}
 
+    # ------------------------------------------------------------------ secondary leg: the reference recipe's gradient checkpointing
+    # (stage2/base.py:99 `gradient_checkpointing=True`, modeling_dreamllm.py:994-1003): whole-layer recompute inside _DecoderLayerFn.
+    # Not the headline (288 GB hold the 7B activations: recompute only costs time here); reported so that both modes have a measured
+    # step time and peak.  Same model / optimizer / batch; 1 warm-up + 2 timed steps.
+    grad_ckpt = None
+    if not a.no_train and not a.no_grad_ckpt_leg and not tiny and world == 1:
+        try:
+            model.gradient_checkpointing_enable()
+            step()
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                out_c = step()
+            torch.cuda.synchronize()
+            dtc = time.perf_counter() - t0
+            grad_ckpt = dict(metric="interleaved train samples/sec with gradient_checkpointing_enable() (whole-layer recompute)",
+                             value=round(a.batch * 2 / dtc, 4), unit="samples/s", steps=2, ms_per_step=round(1e3 * dtc / 2, 3),
+                             peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1), loss=float(out_c.loss.item()),
+                             vs_keeping_path=round((a.batch * 2 / dtc) / train["value"], 4) if train.get("value") else None)
+        except Exception as ex:
+            grad_ckpt = {"error": repr(ex)}
+        finally:
+            model.gradient_checkpointing_disable()
+
     # ------------------------------------------------------------------ the other BASELINE.json configs (N = 1 only, short)
     configs = None
     if world == 1 and not tiny and not a.no_configs:
@@ -483,7 +509,8 @@ def main():
                        "model": "dreamllm-7b" if not tiny else "tiny", "global_batch": world * a.batch, "per_gpu_batch": a.batch,
                        "seq_len": a.seq_len if not tiny else 512, "images_per_sample": a.images_per_sample,
                        "parallelism": f"dp{world}" + ("-shardedgrad" if (a.sharded_grad and world > 1) else ""), "optimizer": "AdamW bf16 states + global-norm clip 1.0",
-                       "activation_recompute": "none (no layer checkpointing; normed inputs and the SwiGLU product are kept: +40 GB, peak_hbm_gb)"},
+                       "activation_recompute": "none in the headline leg (normed inputs and the SwiGLU product are kept: +40 GB, peak_hbm_gb); "
+                                               "the reference recipe's gradient checkpointing is measured beside it: train_grad_ckpt"},
             "loss": train.get("loss"),
             "roofline": train.get("roofline"),
             "e2e_frac_mfma_peak": train.get("e2e_frac_mfma_peak"),
@@ -496,6 +523,7 @@ def main():
             "comm_exposed_ms": (train.get("comm") or {}).get("comm_exposed_ms"),
             "comm": train.get("comm"),
             "train_ragged": ragged,
+            "train_grad_ckpt": grad_ckpt,
             "denoise": denoise,
             "configs": configs,
         }

@@ -56,7 +56,7 @@ SIGNATURES = {
     "dllm_adamw_multi": [c_void_p] * 5 + [c_int] + [c_float] * 5 + [c_int, c_float, c_void_p, c_void_p],
     "dllm_sumsq_multi": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "dllm_reduce_sum_f32": [c_void_p, c_i64, c_void_p, c_void_p],
-    "dllm_mse_sum": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p],
+    "dllm_mse_sum": [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p],
     "dllm_mse_bwd": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p],
     "dllm_add_bcast": [c_void_p] * 3 + [c_i64, c_i64, c_void_p],
     "dllm_add_rowgroup": [c_void_p] * 3 + [c_i64, c_i64, c_int, c_void_p],

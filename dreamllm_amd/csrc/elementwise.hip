@@ -470,9 +470,10 @@ __global__ __launch_bounds__(256) void reduce_sum_f32_kernel(const float* __rest
     if (threadIdx.x == 0) out[0] = s;
 }
 
-// mean((a - b)^2) partial sums: out += sum (a-b)^2 ; dgrad (optional): da = 2 (a - b) * gscale[0] / n
+// mean((a - b)^2): per-block partial sums partials[block] = sum (a-b)^2 over the block's grid-stride elements (the caller adds them up in
+// index order: dllm_reduce_sum_f32 -- no float atomics, bit-identical run to run) ; dgrad: da = 2 (a - b) * gscale[0] / n
 __global__ __launch_bounds__(256) void mse_kernel(const bf16* __restrict__ a, const float* __restrict__ b, int64_t n,
-                                                  float* __restrict__ out) {
+                                                  float* __restrict__ partials) {
     __shared__ float scratch[4];
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -480,7 +481,7 @@ __global__ __launch_bounds__(256) void mse_kernel(const bf16* __restrict__ a, co
         s += d * d;
     }
     s = block_sum<4>(s, scratch);
-    if (threadIdx.x == 0) atomicAdd(out, s);
+    if (threadIdx.x == 0) partials[blockIdx.x] = s;
 }
 __global__ __launch_bounds__(256) void mse_bwd_kernel(const bf16* __restrict__ a, const float* __restrict__ b, int64_t n,
                                                       const float* __restrict__ gscale, bf16* __restrict__ da) {
@@ -831,13 +832,11 @@ int dllm_reduce_sum_f32(const float* in, int64_t n, float* out, void* stream) {
     return dllm_check_launch();
 }
 
-// out (zeroed fp32 scalar) += sum (pred - target)^2 ; pred bf16, target fp32
-int dllm_mse_sum(const void* pred, const float* target, int64_t n, float* out, void* stream) {
-    if (n < 0) return DLLM_ERR_SHAPE;
-    if (n == 0) return DLLM_OK;
-    int g = grid_for(n);
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(mse_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)pred, target, n, out);
+// partials[0 .. nparts) := per-block sums of (pred - target)^2 (pred bf16, target fp32), 1 <= nparts <= 1024 blocks of 256 threads walking
+// the n elements grid-stride; sum(partials) in index order (dllm_reduce_sum_f32) is the deterministic total
+int dllm_mse_sum(const void* pred, const float* target, int64_t n, float* partials, int nparts, void* stream) {
+    if (n < 0 || nparts < 1 || nparts > 1024) return DLLM_ERR_SHAPE;
+    hipLaunchKernelGGL(mse_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, (const bf16*)pred, target, n, partials);
     return dllm_check_launch();
 }
 int dllm_mse_bwd(const void* pred, const float* target, int64_t n, const float* gscale, void* dpred, void* stream) {

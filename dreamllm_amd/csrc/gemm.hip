@@ -637,24 +637,75 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
         }
     }
 
-    auto issue = [&](int64_t k0, int buf) {
+    // ---- LDS-DMA requests of the dense operands: buffer_load_dwordx4 ... offen lds (round 6).  The request carries a wave-uniform
+    // buffer descriptor (the operand's origin for the K tile, advanced by SALU once per tile) and ONE 32-bit per-lane byte offset that never
+    // changes: no 64-bit VALU address arithmetic per request, half the address VGPRs read at issue.  tools/dma_issue_probe.hip (8 waves,
+    // 8 MFMAs per request, L2-resident panels shared by an XCD's blocks as in a GEMM cluster): 303 clk per iteration against 337 for
+    // global_load_lds_dwordx4 with 64-bit per-lane addresses and 308 for no request at all (profiles/r06_dma_issue_probe.log).
+    // Offsets: A_K / B_K image = rows of the tile x 128 bytes of k (descriptor at (row0, k0), offset (r * ld + 8 c) * 2, r < 256);
+    // A_M / B_N image = 64 k rows x the tile's 512 bytes (descriptor at (k0, 0), offset (krow * ld + col) * 2).  Rows / columns past
+    // the edge are clamped as before (they only feed outputs that are never stored).
+    constexpr bool BUFA = (AL == A_K || AL == A_M);
+    uint32_t voA[4], voB[NBD];
+    uint64_t curA = 0, curB = 0, stepA = 0, stepB = 0;   // byte address of the descriptor origin for the NEXT K tile to request; per-tile advance
+    if constexpr (BUFA) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int grp = wave * 4 + q;
+            if constexpr (AL == A_K) {
+                const int r = grp * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                const int64_t rr = min((int64_t)r, P.M - 1 - m0);
+                voA[q] = (uint32_t)((rr * P.lda + c * 8) * 2);
+            } else {
+                const int krow = grp * 2 + (lane >> 5);
+                const int pos = (lane & 31) * 16;
+                const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+                const int lbyte = ((((pos >> 5) ^ f)) << 5) + (pos & 31);
+                const int64_t col = min(m0 + (lbyte >> 1), P.M - 8);
+                voA[q] = (uint32_t)((krow * P.lda + col) * 2);
+            }
+        }
+        curA = (uint64_t)(uintptr_t)P.A + (uint64_t)((AL == A_K ? m0 * P.lda + (int64_t)kt0 * BK : (int64_t)kt0 * BK * P.lda) * 2);
+        stepA = (uint64_t)((AL == A_K ? (int64_t)BK : (int64_t)BK * P.lda) * 2);
+    }
+#pragma unroll
+    for (int q = 0; q < NBD; ++q) {
+        if constexpr (BL == B_K) {
+            const int grp = (BN == 128 ? wave * NBD : wave * 4) + q;
+            const int r = grp * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            const int64_t rr = min((int64_t)r, P.N - 1 - n0);
+            voB[q] = (uint32_t)((rr * P.ldb + c * 8) * 2);
+        } else {
+            const int grp = wave * 4 + q;
+            const int krow = grp * 2 + (lane >> 5);
+            const int pos = (lane & 31) * 16;
+            const int f = (krow & 3) | (((krow >> 3) & 1) << 2);
+            const int lbyte = ((((pos >> 5) ^ f)) << 5) + (pos & 31);
+            const int64_t col = min(n0 + (lbyte >> 1), P.N - 8);
+            voB[q] = (uint32_t)((krow * P.ldb + col) * 2);
+        }
+    }
+    curB = (uint64_t)(uintptr_t)P.B + (uint64_t)((BL == B_K ? n0 * P.ldb + (int64_t)kt0 * BK : (int64_t)kt0 * BK * P.ldb) * 2);
+    stepB = (uint64_t)((BL == B_K ? (int64_t)BK : (int64_t)BK * P.ldb) * 2);
+    auto dma_buf = [&](uint64_t origin, uint32_t vo, char* dst) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)origin, 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, 0, 0, 0);
+    };
+
+    auto issue = [&](int64_t k0, int buf) {   // the whole first tile (prologue): k0 is the tile curA / curB point at
         char* ta = smem + buf * STAGE;
         char* tb = ta + TILE_BYTES;
-        if constexpr (AL == A_K)
-            glds_kc_tile(P.A, P.lda, m0, P.M, k0, ta, wave, lane);
-        else if constexpr (AL == A_M)
-            glds_mc_tile(P.A, P.lda, m0, P.M, k0, ta, wave, lane);
-        else {
+        if constexpr (BUFA) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma_buf(curA, voA[q], ta + (wave * 4 + q) * 1024);
+        } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) glds_conv_one<SHIFT>(P.A, P.cv, cdma, (int)(k0 / P.cv.C), (int)(k0 % P.cv.C), ta, wave, lane, q);
         }
-        if constexpr (BN == 128) {
 #pragma unroll
-            for (int q = 0; q < NBD; ++q) glds_kc_grp(P.B, P.ldb, n0, P.N, k0, tb, wave * NBD + q, lane);
-        } else if constexpr (BL == B_K)
-            glds_kc_tile(P.B, P.ldb, n0, P.N, k0, tb, wave, lane);
-        else
-            glds_mc_tile(P.B, P.ldb, n0, P.N, k0, tb, wave, lane);
+        for (int q = 0; q < NBD; ++q) dma_buf(curB, voB[q], tb + ((BN == 128 ? wave * NBD : wave * 4) + q) * 1024);
     };
 
     // per-lane byte offset of fragment (idx 0, k step 0) inside an operand tile
@@ -672,24 +723,17 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
         fragr_issue<AMC, 0, 0>(fa[0], ab);
     };
 
-    // q-th of the wave's 8 DMA instructions for one K tile (4 per operand)
-    auto issue_one = [&](int64_t k0, int buf, int q) {
+    // q-th of the wave's 8 DMA instructions for the K tile curA / curB point at (4 per operand)
+    auto issue_one = [&](int buf, int q) {
         char* ta = smem + buf * STAGE;
         char* tb = ta + TILE_BYTES;
         if (q < 4) {
-            if constexpr (AL == A_K)
-                glds_kc_one(P.A, P.lda, m0, P.M, k0, ta, wave, lane, q);
-            else if constexpr (AL == A_M)
-                glds_mc_one(P.A, P.lda, m0, P.M, k0, ta, wave, lane, q);
+            if constexpr (BUFA)
+                dma_buf(curA, voA[q], ta + (wave * 4 + q) * 1024);
             else
                 glds_conv_one<SHIFT>(P.A, P.cv, cdma, ctap, cci, ta, wave, lane, q);
         } else {
-            if constexpr (BN == 128)
-                glds_kc_grp(P.B, P.ldb, n0, P.N, k0, tb, wave * NBD + (q - 4), lane);
-            else if constexpr (BL == B_K)
-                glds_kc_one(P.B, P.ldb, n0, P.N, k0, tb, wave, lane, q - 4);
-            else
-                glds_mc_one(P.B, P.ldb, n0, P.N, k0, tb, wave, lane, q - 4);
+            dma_buf(curB, voB[q - 4], tb + ((BN == 128 ? wave * NBD : wave * 4) + (q - 4)) * 1024);
         }
     };
 
@@ -701,7 +745,10 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
     for (int t = kt0; t < kt1; ++t) {
         // tile t+1 goes into the buffer tile t-1 was read from: every wave finished those reads before the last barrier
         const bool pf = (t + 1 < kt1) && P.dbg_noload != 1;
-        const int64_t kpf = P.dbg_noload == 2 ? (int64_t)0 : (int64_t)(t + 1) * BK;
+        if (P.dbg_noload != 2) {   // (bench mode 2: every prefetch re-reads the first K tile)
+            curA += stepA;
+            curB += stepB;
+        }
         const int nbuf = (t - kt0 + 1) & 1;
         if constexpr (CONV) {  // K tile t+1 starts BK channels further; wraps into the next tap at C
             cci += BK;
@@ -713,7 +760,7 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
         static_for<0, NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
             if constexpr (g < 4 + NBD) {  // one DMA instruction per group from the start of the tile: no 64-KiB burst per CU
-                if (pf) issue_one(kpf, nbuf, g);
+                if (pf) issue_one(nbuf, g);
             }
             if constexpr (g < NG - 1) {
                 constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;

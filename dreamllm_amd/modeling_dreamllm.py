@@ -174,7 +174,11 @@ class _DecoderLayerFn(torch.autograd.Function):
     unpacked weights the layer falls back to one GEMM per projection (identical results up to the GEMM's own rounding)."""
 
     @staticmethod
-    def forward(ctx, x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, n_heads, n_kv, eps, want_kv):
+    def _run_forward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, n_heads, n_kv, eps, need_bwd, ng,
+                     keep, want_y=True):
+        """The layer's forward launches.  Returns (y, (k, v) views of the packed q|k|v buffer, the intermediates the backward reads).
+        `want_y=False` (the recompute pass of `gradient_checkpointing`) stops in front of the down projection: nothing behind it is
+        needed by the backward."""
         B, S, Hd = x.shape
         hd = Hd // n_heads
         T = B * S
@@ -189,10 +193,7 @@ class _DecoderLayerFn(torch.autograd.Function):
             ops.gemm(h2d, wq, T, nq, Hd, Hd, Hd, 0, 0, out=o2d[:, :nq])
             ops.gemm(h2d, wk, T, nkv, Hd, Hd, Hd, 0, 0, out=o2d[:, nq:nq + nkv])
             ops.gemm(h2d, wv, T, nkv, Hd, Hd, Hd, 0, 0, out=o2d[:, nq + nkv:])
-        need_bwd = any(ctx.needs_input_grad[:10])
-        ng = ctx.needs_input_grad          # kept tensors only feed weight gradients (a frozen LLM keeps nothing extra)
-        keep = need_bwd and KEEP_LAYER_ACTIVATIONS
-        h_keep = h if (keep and (ng[2] or ng[3] or ng[4])) else None
+        h_keep = h if (keep and (ng[2] or ng[3] or ng[4])) else None   # kept tensors only feed weight gradients (a frozen LLM keeps nothing extra)
         del h
         qk = qkv[:, :, : nq + nkv].unflatten(-1, (n_heads + n_kv, hd))   # q heads then k heads: one RoPE launch
         ops.rope_(qk, cos, sin, pos)
@@ -213,12 +214,32 @@ class _DecoderLayerFn(torch.autograd.Function):
             ops.gemm(h22, wu, T, F_, Hd, Hd, Hd, 0, 0, out=gu[:, F_:])
         h2_keep = h2 if (keep and (ng[7] or ng[8])) else None
         del h2
-        act = ops.glu_fwd(gu[:, :F_], gu[:, F_:], 0)
-        y = ops.linear_fwd(act.view(B, S, F_), wd, residual=x2)
+        y = act = None
+        if want_y or (keep and ng[9]):
+            act = ops.glu_fwd(gu[:, :F_], gu[:, F_:], 0)
+        if want_y:
+            y = ops.linear_fwd(act.view(B, S, F_), wd, residual=x2)
+        return y, (k, v), (rstd1, qkv, o, lse, x2, rstd2, gu, h_keep, h2_keep, act if (keep and ng[9]) else None)
+
+    @staticmethod
+    def forward(ctx, x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, n_heads, n_kv, eps, want_kv,
+                recompute=False):
+        need_bwd = any(ctx.needs_input_grad[:10])
+        ng = ctx.needs_input_grad
+        # `recompute` = whole-layer activation recompute (the reference's gradient checkpointing, modeling_dreamllm.py:994-1003,
+        # stage2/base.py:99): only the layer input is kept; the backward re-runs the forward launches (all but the down projection)
+        # and then proceeds as usual -- same kernels on the same inputs, so the gradients are bit-identical to the keeping path.
+        recompute = bool(recompute) and need_bwd
+        keep = need_bwd and KEEP_LAYER_ACTIVATIONS and not recompute
+        y, (k, v), inter = _DecoderLayerFn._run_forward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart,
+                                                        n_heads, n_kv, eps, need_bwd, ng, keep)
         if need_bwd:
-            ctx.save_for_backward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, qkv, o, lse,
-                                  x2, rstd2, gu, h_keep, h2_keep, act if (keep and ng[9]) else None)
+            if recompute:
+                ctx.save_for_backward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart)
+            else:
+                ctx.save_for_backward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, *inter)
             ctx.cfg = (n_heads, n_kv, eps)
+            ctx.recompute = recompute
         if want_kv:
             k, v = k.contiguous(), v.contiguous()  # the cache must not pin the packed q/k/v buffer
             ctx.mark_non_differentiable(k, v)
@@ -227,9 +248,17 @@ class _DecoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dk, _dv):
-        (x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, qkv, o, lse, x2, rstd2,
-         gu, h_keep, h2_keep, act_keep) = ctx.saved_tensors
         n_heads, n_kv, eps = ctx.cfg
+        if ctx.recompute:
+            x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart = ctx.saved_tensors
+            with torch.no_grad():   # intermediates of this layer only: freed again when this backward returns
+                _, _, inter = _DecoderLayerFn._run_forward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart,
+                                                           n_heads, n_kv, eps, True, ctx.needs_input_grad, KEEP_LAYER_ACTIVATIONS,
+                                                           want_y=False)
+            rstd1, qkv, o, lse, x2, rstd2, gu, h_keep, h2_keep, act_keep = inter
+        else:
+            (x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, qkv, o, lse, x2, rstd2,
+             gu, h_keep, h2_keep, act_keep) = ctx.saved_tensors
         B, S, Hd = x.shape
         hd = Hd // n_heads
         T = B * S
@@ -308,7 +337,7 @@ class _DecoderLayerFn(torch.autograd.Function):
             ops.gemm(d2[:, nq:nq + nkv], wk, T, Hd, nkv, ld, Hd, 0, 1, out=dh, accumulate=True)
             ops.gemm(d2[:, nq + nkv:], wv, T, Hd, nkv, ld, Hd, 0, 1, out=dh, accumulate=True)
         dx, dw_in = ops.rmsnorm_bwd(dh, x, w_in, rstd1, dh_in=dx2, need_dw=need[1])
-        return (dx.view(x.shape), dw_in, dwq, dwk, dwv, dwo, dw_post, dwg, dwu, dwd) + (None,) * 9
+        return (dx.view(x.shape), dw_in, dwq, dwk, dwv, dwo, dw_post, dwg, dwu, dwd) + (None,) * 10
 
 
 class DreamLLMMLP(nn.Module):
@@ -553,7 +582,8 @@ class DreamLLMDecoderLayer(nn.Module):
                 hidden_states.contiguous(), self.input_layernorm.weight, a.q_proj.weight, a.k_proj.weight, a.v_proj.weight,
                 a.o_proj.weight, self.post_attention_layernorm.weight, self.mlp.gate_proj.weight, self.mlp.up_proj.weight,
                 self.mlp.down_proj.weight, cos, sin, pos, seqlens, seqstart, a.num_heads, a.num_key_value_heads,
-                self.input_layernorm.variance_epsilon, bool(use_cache))
+                self.input_layernorm.variance_epsilon, bool(use_cache),
+                bool(kwargs.get("recompute", False)) and self.training and torch.is_grad_enabled())
             outputs = (y,)
             if use_cache:
                 outputs += ((k.transpose(1, 2), v.transpose(1, 2)),)
@@ -829,6 +859,12 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
         next_decoder_cache = () if use_cache else None
         additional_log_info = {}
         extra = {}
+        if self.gradient_checkpointing and self.training:
+            # modeling_dreamllm.py:972-976,994-1003 (`gradient_checkpointing_enable()`, stage2/base.py:99): whole-layer activation
+            # recompute, done inside _DecoderLayerFn (only each layer's input stays resident) instead of torch.utils.checkpoint
+            use_cache = False
+            next_decoder_cache = None
+            extra["recompute"] = True
         if torch.compiler.is_compiling() and not torch.is_grad_enabled() and past_key_values is None and len(self.layers) > 0:
             extra["rope_tables"] = self.layers[0].self_attn.rotary_emb.tables(seq_length, hidden_states.device)
         for idx, decoder_layer in enumerate(self.layers):

@@ -1289,10 +1289,13 @@ class MSELossFn(torch.autograd.Function):
     def forward(ctx, pred, target):
         pred = pred.contiguous()
         target = target.contiguous()
-        acc = torch.zeros(1, dtype=torch.float32, device=pred.device)
-        check("dllm_mse_sum", _p(pred), _p(target), pred.numel(), _p(acc), _stream())
+        n = pred.numel()
+        nparts = max(1, min(1024, (n + 2047) // 2048))           # >= 8 elements per thread; summed in index order below (deterministic)
+        parts = torch.empty(nparts, dtype=torch.float32, device=pred.device)
+        check("dllm_mse_sum", _p(pred), _p(target), n, _p(parts), nparts, _stream())
+        acc = reduce_sum_f32(parts)
         ctx.save_for_backward(pred, target)
-        return (acc / pred.numel()).reshape(())
+        return (acc / max(n, 1)).reshape(())
 
     @staticmethod
     def backward(ctx, dloss):

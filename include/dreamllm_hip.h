@@ -196,8 +196,9 @@ int dllm_cross_entropy(const float* logits, const int64_t* labels, float* loss_r
 /* softmax(dim=-1) of fp32 scores -> bf16 probabilities: the single-head, 512-wide mid-block attention of AutoencoderKL [ext]
  * (modeling_plugins.py:511,842), whose head_dim is outside the flash kernels: scores and P V run on dllm_gemm_bf16. */
 int dllm_softmax_rows(const float* x, void* y, int64_t rows, int cols, int64_t ld_x, int64_t ld_y, void* stream);
-/* F.mse_loss(model_pred.float(), target.float()), modeling_plugins.py:559: out += sum (pred - target)^2 ; and its grad */
-int dllm_mse_sum(const void* pred, const float* target, int64_t n, float* out, void* stream);
+/* F.mse_loss(model_pred.float(), target.float()), modeling_plugins.py:559: partials[b] = sum over block b's elements of (pred - target)^2
+   (nparts <= 1024 blocks; the total is dllm_reduce_sum_f32 over the partials: fixed order, no float atomics) ; and its grad */
+int dllm_mse_sum(const void* pred, const float* target, int64_t n, float* partials, int nparts, void* stream);
 int dllm_mse_bwd(const void* pred, const float* target, int64_t n, const float* gscale, void* dpred, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------- optimizer step

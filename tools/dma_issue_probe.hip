@@ -44,7 +44,12 @@ __global__ __launch_bounds__(NW * 64) void probe(const char* src, float* out, ui
     // per-lane source: row (lane >> 3) of an 8-row x 128-byte group, 16-byte chunk (lane & 7), row pitch 8 KiB (a K = 4096 bf16 operand)
     const uint32_t voff = (uint32_t)((lane >> 3) * 8192 + (lane & 7) * 16 + wave * 65536);
     // small windows: four blocks share a 1-MiB region (L1 / L2 hits); large windows: every block streams its own slice of `src`
-    const char* blk = src + (window <= 4096u ? (size_t)(blockIdx.x & 3) * (1u << 20) : (size_t)blockIdx.x * (size_t)window * 1u);
+    // `shared` != 0: the 32 blocks of an XCD (blockIdx & 7) walk ONE region together, as the tiles of a GEMM cluster share their panels
+    // through the XCD's L2 (shared = 1: all 32 read the same bytes; shared = 2: four groups of 8 blocks, the A-panel / B-panel mix)
+    const bool shared = (window >> 31) != 0;
+    window &= 0x7fffffffu;
+    const char* blk = src + (shared ? (size_t)(blockIdx.x & 7) * (size_t)window + (size_t)((blockIdx.x >> 3) & 3) * 131072u
+                                    : (window <= 4096u ? (size_t)(blockIdx.x & 3) * (1u << 20) : (size_t)blockIdx.x * (size_t)window * 1u));
     const char* vaddr = blk + voff;
     const uint32_t lds_dst = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)wave * 1024u;
     const uint64_t base64 = (uint64_t)(uintptr_t)blk;
@@ -106,7 +111,8 @@ static void run(const char* tag, const char* src, float* out, uint64_t* stamps, 
     }
     uint64_t h[8];
     hipMemcpy(h, stamps, sizeof(h), hipMemcpyDeviceToHost);
-    printf("%-40s w/SIMD %d MFMA/req %2d depth %2d reads %d window %8u : wave0 %7.1f clk/iter", tag, NW / 4, NM, DEPTH, NRD, window, (double)h[0] / rep);
+    printf("%-40s w/SIMD %d MFMA/req %2d depth %2d reads %d window %8u%s : wave0 %7.1f clk/iter", tag, NW / 4, NM, DEPTH, NRD, window & 0x7fffffffu,
+           (window >> 31) ? " shared/XCD" : "", (double)h[0] / rep);
     if (NW == 8) printf("   wave4 %7.1f", (double)h[4] / rep);
     printf("\n");
 }
@@ -143,6 +149,13 @@ int main() {
     ROW2(4, 3, W3)
     ROW2(16, 3, W3)
     ROW2(8, 0, W3)
+    // the GEMM's sharing pattern: the blocks of an XCD read the same region (L2 hits after the first toucher), window = what an XCD walks
+    const uint32_t SH = 0x80000000u;
+    ROW2(8, 3, SH | (1u << 20))
+    ROW2(8, 3, SH | (4u << 20))
+    ROW2(8, 3, SH | (16u << 20))
+    ROW2(16, 3, SH | (4u << 20))
+    ROW2(4, 3, SH | (4u << 20))
     hipError_t e = hipGetLastError();
     printf("last error: %s\n", hipGetErrorString(e));
     return 0;
