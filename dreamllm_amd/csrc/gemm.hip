@@ -605,6 +605,15 @@ __device__ __forceinline__ void glds_conv_one(const bf16* x, const ConvGeom& g, 
 //
 // pipe_tile: the K loop of ONE output tile over the K tiles [kt0, kt1) (kt1 > kt0), accumulating into `acc`.  The whole-tile
 // kernel calls it with [0, K / 64); the stream-K tail kernel with a slice of a tile's K loop.
+// LDS operations issued AFTER the read of A fragment g inside a K tile, with a lookahead of `la` groups: A(g + 1 .. g + la) and the four B
+// fragments that go out in front of the first A fragment of a k step
+constexpr int pipe_younger_ops(int g, int la, int ng, int mi, int oa, int ob) {
+    int n = 0;
+    for (int j = 1; j <= la; ++j)
+        if (g + j < ng) n += oa + ((g + j) % mi == 0 ? 4 * ob : 0);
+    return n;
+}
+
 template <int BN_>
 struct PipeGeom {
     static constexpr int WC = BN_ / 64, MI = (256 / (8 / WC)) / 16;  // wave grid (8 / WC) x WC, MI 16-row MFMA tiles per wave
@@ -669,13 +678,19 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
         curA = (uint64_t)(uintptr_t)P.A + (uint64_t)((AL == A_K ? m0 * P.lda + (int64_t)kt0 * BK : (int64_t)kt0 * BK * P.lda) * 2);
         stepA = (uint64_t)((AL == A_K ? (int64_t)BK : (int64_t)BK * P.lda) * 2);
     }
+    // EPI_SWIGLU_FWD: the B tile's 256 rows are re-mapped so that every wave holds 32 gate columns and the 32 up columns of the SAME
+    // outputs (tile row r of wave column block r >> 6: rows 0-31 = gate rows, 32-63 = the matching up rows F further down the packed
+    // weight); block column pid_n then covers the outputs [n0 / 2, n0 / 2 + 128).  Free on the DMA's per-lane offset.
+    bool glu_map = false;
+    if constexpr (AL == A_K && BL == B_K && BN == 256) glu_map = P.epi == EPI_SWIGLU_FWD;
 #pragma unroll
     for (int q = 0; q < NBD; ++q) {
         if constexpr (BL == B_K) {
             const int grp = (BN == 128 ? wave * NBD : wave * 4) + q;
             const int r = grp * 8 + (lane >> 3);
             const int c = (lane & 7) ^ ((r >> 1) & 7);
-            const int64_t rr = min((int64_t)r, P.N - 1 - n0);
+            int64_t rr = min((int64_t)r, P.N - 1 - n0);
+            if (glu_map) rr = ((r & 32) ? P.glu_F : 0) + (r >> 6) * 32 + (r & 31);   // relative to weight row n0 / 2 (the descriptor origin below)
             voB[q] = (uint32_t)((rr * P.ldb + c * 8) * 2);
         } else {
             const int grp = wave * 4 + q;
@@ -687,7 +702,7 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
             voB[q] = (uint32_t)((krow * P.ldb + col) * 2);
         }
     }
-    curB = (uint64_t)(uintptr_t)P.B + (uint64_t)((BL == B_K ? n0 * P.ldb + (int64_t)kt0 * BK : (int64_t)kt0 * BK * P.ldb) * 2);
+    curB = (uint64_t)(uintptr_t)P.B + (uint64_t)((BL == B_K ? (glu_map ? (n0 >> 1) : n0) * P.ldb + (int64_t)kt0 * BK : (int64_t)kt0 * BK * P.ldb) * 2);
     stepB = (uint64_t)((BL == B_K ? (int64_t)BK : (int64_t)BK * P.ldb) * 2);
     auto dma_buf = [&](uint64_t origin, uint32_t vo, char* dst) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)origin, 0, 0x7fffffff, 0x00020000);
@@ -715,25 +730,31 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
     const uint32_t offB =
         (uint32_t)TILE_BYTES + (BMC ? (uint32_t)mc_off<T>(lg * 8 + (lt >> 2), wn * 2 + (lt & 3) * 8) : (uint32_t)kc_off(wn + lt, lg));
 
-    FragR<AMC> fa[2];
+    // A fragments are requested LA groups ahead of their MFMAs (round 6: 2; rounds 1-5: 1 = 64 matrix cycles, less than an LDS round trip
+    // under load) into a ring of 4 (NG % 4 == 0: the slots of a tile's last groups never collide with the first reads of the next tile,
+    // which are issued in front of the last group's MFMAs); the B fragments of a k step go out in front of the first A fragment of that step.
+    constexpr int LA = 2;
+    static_assert(NG % 4 == 0 && LA <= 2, "ring of 4 A-fragment slots");
+    FragR<AMC> fa[4];
     FragR<BMC> fb[2][4];
     uint32_t ab = s0 + offA, bb = s0 + offB;
     auto first_reads = [&]() {
         static_for<0, 4>([&](auto j) { fragr_issue<BMC, decltype(j)::value, 0>(fb[0][decltype(j)::value], bb); });
-        fragr_issue<AMC, 0, 0>(fa[0], ab);
+        static_for<0, LA>([&](auto g0) { fragr_issue<AMC, decltype(g0)::value % MI, decltype(g0)::value / MI>(fa[decltype(g0)::value], ab); });
     };
 
     // q-th of the wave's 8 DMA instructions for the K tile curA / curB point at (4 per operand)
-    auto issue_one = [&](int buf, int q) {
+    auto issue_one = [&](int buf, int q, const __amdgpu_buffer_rsrc_t& ra, const __amdgpu_buffer_rsrc_t& rb) {
         char* ta = smem + buf * STAGE;
         char* tb = ta + TILE_BYTES;
         if (q < 4) {
             if constexpr (BUFA)
-                dma_buf(curA, voA[q], ta + (wave * 4 + q) * 1024);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (__attribute__((address_space(3))) void*)(ta + (wave * 4 + q) * 1024), 16, (int)voA[q], 0, 0, 0);
             else
                 glds_conv_one<SHIFT>(P.A, P.cv, cdma, ctap, cci, ta, wave, lane, q);
         } else {
-            dma_buf(curB, voB[q - 4], tb + ((BN == 128 ? wave * NBD : wave * 4) + (q - 4)) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(tb + ((BN == 128 ? wave * NBD : wave * 4) + (q - 4)) * 1024), 16,
+                                                     (int)voB[q - 4], 0, 0, 0);
         }
     };
 
@@ -742,15 +763,32 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
     __builtin_amdgcn_s_barrier();
     first_reads();
 
-    for (int t = kt0; t < kt1; ++t) {
+    // The body of K tile t.  NEXT = a tile t + 1 follows: its requests ride on the first 4 + NBD MFMA groups and the tile barrier + the first
+    // fragment reads of tile t + 1 sit in front of the last group.  The last tile of the range runs the NEXT = false copy, so the loop itself
+    // carries no per-request branch (round 6; the shipped loop tested `t + 1 < kt1` in front of each of the 8 requests).
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    auto body = [&](int t, auto next_c) {
+        constexpr bool NEXT = decltype(next_c)::value;
         // tile t+1 goes into the buffer tile t-1 was read from: every wave finished those reads before the last barrier
-        const bool pf = (t + 1 < kt1) && P.dbg_noload != 1;
-        if (P.dbg_noload != 2) {   // (bench mode 2: every prefetch re-reads the first K tile)
+#ifdef DLLM_BENCH_MODES
+        const bool pf = NEXT && P.dbg_noload != 1;
+        if (NEXT && P.dbg_noload != 2) {   // (bench mode 2: every prefetch re-reads the first K tile)
             curA += stepA;
             curB += stepB;
         }
+#else
+        constexpr bool pf = NEXT;
+        if constexpr (NEXT) {
+            curA += stepA;
+            curB += stepB;
+        }
+#endif
+        if constexpr (NEXT) {   // the two descriptors of tile t + 1: built once per tile (wave-uniform SALU), shared by its 4 + NBD requests
+            if constexpr (BUFA) rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)curA, 0, 0x7fffffff, 0x00020000);
+            rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)curB, 0, 0x7fffffff, 0x00020000);
+        }
         const int nbuf = (t - kt0 + 1) & 1;
-        if constexpr (CONV) {  // K tile t+1 starts BK channels further; wraps into the next tap at C
+        if constexpr (CONV && NEXT) {  // K tile t+1 starts BK channels further; wraps into the next tap at C
             cci += BK;
             if (cci >= P.cv.C) {
                 cci -= P.cv.C;
@@ -759,18 +797,25 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
         }
         static_for<0, NG>([&](auto gc) {
             constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
-            if constexpr (g < 4 + NBD) {  // one DMA instruction per group from the start of the tile: no 64-KiB burst per CU
-                if (pf) issue_one(nbuf, g);
+            // one DMA instruction per group from the start of the tile: no 64-KiB burst per CU.  (Round 6, with the cheaper buffer form: two per
+            // group in the first four groups measured -6 % on the weight gradients, -1...-3 % dgrad, -4...+0.7 % forward:
+            // profiles/r06_gemm_rpg2_ab.log)
+            if constexpr (NEXT && g < 4 + NBD) {
+                if (pf) issue_one(nbuf, g, rsA, rsB);
             }
-            if constexpr (g < NG - 1) {
-                constexpr int kn = (g + 1) / MI, in = (g + 1) % MI;
+            if constexpr (g + LA < NG) {   // request A(g + LA) (and, in front of the first A fragment of a k step, that step's B fragments)
+                constexpr int kn = (g + LA) / MI, in = (g + LA) % MI;
                 if constexpr (in == 0)
                     static_for<0, 4>([&](auto j) { fragr_issue<BMC, decltype(j)::value, kn>(fb[kn][decltype(j)::value], bb); });
-                fragr_issue<AMC, in, kn>(fa[(g + 1) & 1], ab);
-                fragr_wait<OA + (in == 0 ? 4 * OB : 0)>(fa[g & 1]);
+                fragr_issue<AMC, in, kn>(fa[(g + LA) & 3], ab);
+            }
+            // LDS returns in order: A(g) has landed once at most the operations issued after it are outstanding
+            constexpr int younger = pipe_younger_ops(g, LA, NG, MI, OA, OB);
+            if constexpr (g < NG - 1) {
+                fragr_wait<younger>(fa[g & 3]);
             } else {
-                fragr_wait<0>(fa[g & 1]);
-                if (t + 1 < kt1) {
+                fragr_wait<0>(fa[g & 3]);
+                if constexpr (NEXT) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     ab = s0 + offA + (uint32_t)(nbuf * STAGE);
@@ -779,7 +824,7 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
                 }
             }
             if constexpr (i == 0) static_for<0, 4>([&](auto j) { fragr_touch(fb[kk][decltype(j)::value]); });
-            const bf16x8 va = fragr_value(fa[g & 1]);
+            const bf16x8 va = fragr_value(fa[g & 3]);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fragr_value(fb[kk][j]), va, acc[i][j], 0, 0, 0);
@@ -790,14 +835,128 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
             // (the implicit-GEMM conv layouts take it too: B_img 8 denoise loop 43.14 -> 43.32 steps/s in two interleaved rounds,
             // profiles/r05_denoise_prio_ab.log; on the ring kernel both placements tried there measured equal or slower)
             constexpr bool kPrioLayout = (AL == A_K || AL == A_CONV || AL == A_CONVS) && BL == B_K;
-            if constexpr (kPrioLayout) {   // (the seven other placements measured: profiles/patches/r05_gemm_prio_variants.patch)
+            if constexpr (kPrioLayout && NEXT) {   // (the seven other placements measured: profiles/patches/r05_gemm_prio_variants.patch)
                 if constexpr (g + 1 < 4 + NBD) __builtin_amdgcn_s_setprio(1);
                 else __builtin_amdgcn_s_setprio(0);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
-    }
+    };
+    for (int t = kt0; t + 1 < kt1; ++t) body(t, std::true_type{});
+    body(kt1 - 1, std::false_type{});
     __builtin_amdgcn_s_setprio(0);
+}
+
+// ---- fused SwiGLU epilogues (round 6) ----------------------------------------------------------------------------------------
+// Both keep the arithmetic of the stand-alone kernels (elementwise.hip: glu_fwd_kernel / glu_bwd_kernel) on the SAME bf16-rounded
+// operands, so fused and unfused paths give identical results; what disappears is a launch and its round trip through HBM:
+//   FWD  (gate|up projection): the wave holds gate (acc[i][0..1]) and up (acc[i][2..3]) of 32 outputs x 128 rows; it stores the packed
+//        [M, 2F] gate|up tile the backward reads AND act = silu(gate) * up [M, F] -- glu_fwd (a read of 2 x [M, F] and a launch) is gone;
+//   BWD  (down projection's input gradient): d_act = dy Wd stays in the accumulators; gate / up tiles come in through the wave's LDS
+//        region (row-contiguous 16-byte loads), d gate / d up go out the same way -- the [M, F] d_act tensor (written, then read) and
+//        glu_bwd's launch are gone.
+// Full tiles only (M % 256 == 0; FWD: F % 128 == 0; BWD: F % 256 == 0), 16-byte aligned rows: the entry points check.
+// wl: this wave's LDS region, 16 KiB (two 64-row x 128-byte images, chunk swizzle of gemm_epilogue_lds).
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue_swiglu_fwd(const GemmParams& P, f32x4 (&acc)[MI][4], char* wl, int64_t mw, int64_t n0, int wn,
+                                                         int lane) {
+    bf16* gu = reinterpret_cast<bf16*>(P.C);
+    const int64_t h0 = (n0 >> 1) + (wn >> 6) * 32;   // first of the wave's 32 output columns
+#pragma unroll
+    for (int half = 0; half < MI / 4; ++half) {
+        // pass 1: the packed gate|up tile (64 rows x [32 gate | 32 up]) through the region, rows out as 2 x 64 contiguous bytes
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = half * 4 + ii;
+            const int r = ii * 16 + (lane & 15);
+            const int sw = ((r >> 1) & 7) << 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][j][e] * P.alpha);
+                *reinterpret_cast<bf16x4*>(wl + r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3)) = o;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3), p = lane & 7;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(wl + row * 128 + ((p ^ ((row >> 1) & 7)) << 4));
+            st_bf16x8(gu + (mw + half * 64 + row) * P.ldc + ((p & 4) ? P.glu_F : 0) + h0 + (p & 3) * 8, v);
+        }
+        // pass 2: act from the ROUNDED gate / up (what glu_fwd_kernel reads back from memory), 64 rows x 64 bytes
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = half * 4 + ii;
+            const int r = ii * 16 + (lane & 15);
+            const int sw = ((r >> 1) & 7) << 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = (float)(bf16)(acc[i][j][e] * P.alpha), y = (float)(bf16)(acc[i][j + 2][e] * P.alpha);
+                    o[e] = (bf16)(silu_f(x) * y);
+                }
+                *reinterpret_cast<bf16x4*>(wl + 8192 + r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3)) = o;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 16 + (lane >> 2), p = lane & 3;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(wl + 8192 + row * 128 + ((p ^ ((row >> 1) & 7)) << 4));
+            st_bf16x8(P.aux_out + (mw + half * 64 + row) * P.ld_aux_out + h0 + p * 8, v);
+        }
+    }
+}
+
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmParams& P, f32x4 (&acc)[MI][4], char* wl, int64_t mw, int64_t nw, int lane) {
+    bf16* dgu = reinterpret_cast<bf16*>(P.C);
+    char* w0 = wl;            // gate in, d gate out
+    char* w1 = wl + 8192;     // up in, d up out
+#pragma unroll
+    for (int half = 0; half < MI / 4; ++half) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3), p = lane & 7;
+            const bf16* src = P.aux_in + (mw + half * 64 + row) * P.ld_aux_in + nw + p * 8;
+            const int off = row * 128 + ((p ^ ((row >> 1) & 7)) << 4);
+            *reinterpret_cast<bf16x8*>(w0 + off) = ld_bf16x8(src);
+            *reinterpret_cast<bf16x8*>(w1 + off) = ld_bf16x8(src + P.glu_F);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = half * 4 + ii;
+            const int r = ii * 16 + (lane & 15);
+            const int sw = ((r >> 1) & 7) << 1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int off = r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3);
+                const bf16x4 gv = *reinterpret_cast<const bf16x4*>(w0 + off), uv = *reinterpret_cast<const bf16x4*>(w1 + off);
+                bf16x4 oa, ob;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {   // glu_bwd_kernel<0>, on d_act rounded to bf16 as the unfused path stores it
+                    const float d = (float)(bf16)(acc[i][j][e] * P.alpha), x = (float)gv[e], y = (float)uv[e];
+                    const float sg = sigmoid_f(x);
+                    const float act = x * sg;
+                    const float dact = sg * (1.f + x * (1.f - sg));
+                    oa[e] = (bf16)(d * y * dact);
+                    ob[e] = (bf16)(d * act);
+                }
+                *reinterpret_cast<bf16x4*>(w0 + off) = oa;
+                *reinterpret_cast<bf16x4*>(w1 + off) = ob;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3), p = lane & 7;
+            const int off = row * 128 + ((p ^ ((row >> 1) & 7)) << 4);
+            bf16* dst = dgu + (mw + half * 64 + row) * P.ldc + nw + p * 8;
+            st_bf16x8(dst, *reinterpret_cast<const bf16x8*>(w0 + off));
+            st_bf16x8(dst + P.glu_F, *reinterpret_cast<const bf16x8*>(w1 + off));
+        }
+    }
 }
 
 // Tile `wgid` of the grouped (GROUP_M) tile order -> (pid_m, pid_n)
@@ -842,6 +1001,17 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
 
     pipe_tile<AL, BL, BN_>(P, smem, m0, n0, 0, (int)(P.K / BK), acc);
 
+    if constexpr (AL == A_K && BN_ == 256) {   // fused SwiGLU epilogues (full tiles by construction of their entry points)
+        if (P.epi == (BL == B_K ? EPI_SWIGLU_FWD : EPI_SWIGLU_BWD)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // every wave is done with its fragment reads: the stages become per-wave staging regions
+            if constexpr (BL == B_K)
+                gemm_epilogue_swiglu_fwd<MI>(P, acc, smem + wave * 16384, m0 + wm, n0, wn, lane);
+            else
+                gemm_epilogue_swiglu_bwd<MI>(P, acc, smem + wave * 16384, m0 + wm, n0 + wn, lane);
+            return;
+        }
+    }
     if (epilogue_lds_ok(P, m0, n0, BM, BN)) {
         // every wave must be done with its fragment reads before the stages are reused as per-wave staging regions
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1072,6 +1242,16 @@ static inline bool ring_ok(const GemmParams& P) {
     if (P.dbg_noload != 0 && P.dbg_noload != 4) return false;
     if ((P.K % BK) != 0 || P.K < BK) return false;
     if (AL == A_CONV && (P.cv.C % BK) != 0) return false;
+    // the ring kernel addresses its operands through buffer descriptors with 32-bit byte offsets (round 6); the conv gather additionally relies
+    // on offsets >= 2^31 being out of range (halo taps read zeros): tensors of 2 GiB and more stay on the other kernels
+    constexpr int64_t kLim = (int64_t)1 << 31;
+    if (AL == A_CONV) {
+        if (((int64_t)P.M / ((int64_t)P.cv.OH * P.cv.OW)) * P.cv.H * P.cv.W * P.cv.C * 2 + ((int64_t)P.cv.W + 2) * P.cv.C * 2 >= kLim) return false;
+    } else if (128 * P.lda * 2 + P.K * 2 >= kLim) {
+        return false;
+    }
+    // B rows are addressed relative to the tile's first weight row (GEGLU: the `gate` rows lie N rows behind their `hidden` rows)
+    if (((P.epi == EPI_GEGLU ? P.N : 0) + 128) * P.ldb * 2 + P.K * 2 >= kLim) return false;
     return true;
 }
 
@@ -1291,6 +1471,44 @@ int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bia
     if (layout_a == A_M && layout_b == B_N) return launch_gemm<A_M, B_N>(P, V, s);
     if (layout_a == A_M && layout_b == B_K) return launch_gemm<A_M, B_K>(P, V, s);
     return DLLM_ERR_SHAPE;
+}
+
+// DreamLLMMLP (modeling_dreamllm.py:237) with the SwiGLU folded into the two GEMMs beside it (see gemm_epilogue_swiglu_*).
+//   fwd: gu[M, 2F] = x Wgu^T (Wgu = packed [gate rows; up rows], [2F, K]) and act[M, F] = silu(gu[:, :F]) * gu[:, F:], one launch.
+//   bwd: dgu[M, 2F] = glu_bwd(dy Wd, gu) with Wd [D, F] (the down projection's nn.Linear weight), d_act never stored.
+// Shapes: M % 256 == 0, K (= hidden width, fwd) / D (bwd) a multiple of 64, F % 128 == 0 (fwd) / F % 256 == 0 (bwd); every pointer 16-byte
+// aligned, every leading dimension a multiple of 8.  Anything else: DLLM_ERR_SHAPE / DLLM_ERR_ALIGN (the caller runs the unfused launches).
+int dllm_gemm_swiglu_fwd(const void* x, const void* wgu, void* gu, void* act, int64_t M, int64_t F, int64_t K, int64_t ldx, int64_t ldw,
+                         int64_t ldgu, int64_t ldact, int group_m, void* stream) {
+    if (M <= 0 || F <= 0 || K < BK || (M % 256) || (F % 128) || (K % BK)) return DLLM_ERR_SHAPE;
+    if (!aligned16(x) || !aligned16(wgu) || !aligned16(gu) || !aligned16(act) || ((ldx | ldw | ldgu | ldact) & 7)) return DLLM_ERR_ALIGN;
+    GemmParams P{};
+    P.A = (const bf16*)x; P.B = (const bf16*)wgu; P.C = gu; P.aux_out = (bf16*)act;
+    P.M = M; P.N = 2 * F; P.K = K; P.lda = ldx; P.ldb = ldw; P.ldc = ldgu; P.ld_aux_out = ldact; P.glu_F = F;
+    P.epi = EPI_SWIGLU_FWD; P.alpha = 1.f; P.splitk = 1; P.group_m = group_m > 0 ? group_m : 4;
+    const int64_t tiles = (M / 256) * (2 * F / 256);
+    if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+    constexpr int LDS = 2 * 2 * 256 * BK * 2;
+    static std::atomic<uint64_t> lds_ok{0};
+    dllm_ensure_dyn_lds(&gemm_pipe_kernel<A_K, B_K>, LDS, lds_ok);
+    hipLaunchKernelGGL((gemm_pipe_kernel<A_K, B_K>), dim3((unsigned)tiles), dim3(512), LDS, (hipStream_t)stream, P);
+    return dllm_check_launch();
+}
+int dllm_gemm_swiglu_bwd(const void* dy, const void* wd, const void* gu, void* dgu, int64_t M, int64_t F, int64_t D, int64_t lddy,
+                         int64_t ldw, int64_t ldgu, int64_t lddgu, int group_m, void* stream) {
+    if (M <= 0 || F <= 0 || D < BK || (M % 256) || (F % 256) || (D % BK)) return DLLM_ERR_SHAPE;
+    if (!aligned16(dy) || !aligned16(wd) || !aligned16(gu) || !aligned16(dgu) || ((lddy | ldw | ldgu | lddgu) & 7)) return DLLM_ERR_ALIGN;
+    GemmParams P{};
+    P.A = (const bf16*)dy; P.B = (const bf16*)wd; P.C = dgu; P.aux_in = (const bf16*)gu;
+    P.M = M; P.N = F; P.K = D; P.lda = lddy; P.ldb = ldw; P.ldc = lddgu; P.ld_aux_in = ldgu; P.glu_F = F;
+    P.epi = EPI_SWIGLU_BWD; P.alpha = 1.f; P.splitk = 1; P.group_m = group_m > 0 ? group_m : 4;
+    const int64_t tiles = (M / 256) * (F / 256);
+    if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+    constexpr int LDS = 2 * 2 * 256 * BK * 2;
+    static std::atomic<uint64_t> lds_ok{0};
+    dllm_ensure_dyn_lds(&gemm_pipe_kernel<A_K, B_N>, LDS, lds_ok);
+    hipLaunchKernelGGL((gemm_pipe_kernel<A_K, B_N>), dim3((unsigned)tiles), dim3(512), LDS, (hipStream_t)stream, P);
+    return dllm_check_launch();
 }
 
 // Stream-K tail (splitk <= 1 and workspace != NULL): the workspace must hold dllm_gemm_streamk_ws_bytes() bytes; the library then

@@ -143,22 +143,25 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- per-lane DMA sources: the wave's two 8-row groups of each operand tile -------------------------------------------
-    const bf16* a_src[2];
-    const bf16* b_src[2];
-    int a_chunk[2];
+    // Round 6: requests are buffer_load_dwordx4 ... offen lds -- a wave-uniform descriptor per operand, a 32-bit per-lane byte offset
+    // that is computed ONCE (dense operands, plain conv gather) and the K position in the SGPR offset: no 64-bit per-lane address
+    // arithmetic per request (tools/dma_issue_probe.hip: a request beside 8 MFMAs costs the issuing wave ~25 clk less in this form).
+    // Conv halo: a lane whose tap falls outside the image sends an offset beyond the descriptor's 2^31-byte extent and the hardware
+    // returns zeros (the launcher only sends tensors below 2 GiB here) -- the 16-byte zero page and its 64-bit select are gone.
+    uint32_t a_vo[2], b_vo[2];
     RingConv cdma;
     if constexpr (CONV) ring_conv_init<SHIFT>(cdma, P.cv, m0, P.M, wave, lane);
+    // plain conv gather: offsets are biased by one image row + one pixel so that the (-1, -1) tap of the first pixel stays non-negative
+    const int64_t conv_bias = CONV ? ((int64_t)P.cv.W + 1) * P.cv.C : 0;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int r = (wave * 2 + q) * 8 + (lane >> 3);   // row of the 128-row tile image
         const int c = (lane & 7) ^ ((r >> 1) & 7);        // logical 16-byte chunk held at this lane's LDS position
-        a_chunk[q] = c * 8;
         if constexpr (!CONV) {
-            int64_t row = m0 + r;
-            row = row < P.M ? row : P.M - 1;
-            a_src[q] = P.A + row * P.lda + c * 8;
+            const int64_t rr = min((int64_t)r, P.M - 1 - m0);
+            a_vo[q] = (uint32_t)((rr * P.lda + c * 8) * 2);
         } else {
-            a_src[q] = P.A;
+            a_vo[q] = (uint32_t)((cdma.pix_off[q] + (SHIFT ? 0 : conv_bias) + c * 8) * 2);
         }
         int64_t n;
         if constexpr (GLU) {  // tile rows [64 w, 64 w + 32): `hidden` rows of outputs n0 + 32 w + ..; the next 32: their `gate` rows
@@ -168,8 +171,13 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
             n = n0 + r;
             n = n < P.N ? n : P.N - 1;
         }
-        b_src[q] = P.B + n * P.ldb + c * 8;
+        b_vo[q] = (uint32_t)(((n - n0) * P.ldb + c * 8) * 2);
     }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(uintptr_t)((uint64_t)(uintptr_t)P.A + (uint64_t)((CONV ? (SHIFT ? (int64_t)0 : -conv_bias) : m0 * P.lda) * 2)), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)((uint64_t)(uintptr_t)P.B + (uint64_t)(n0 * P.ldb * 2)), 0, 0x7fffffff, 0x00020000);
+    constexpr uint32_t kOob = 0x80000000u;   // beyond the descriptor's extent: the request returns zeros
     // conv: tap / first channel of the NEXT stage to be issued (advanced incrementally)
     int ctap = 0, cci = 0;
     if constexpr (CONV) {
@@ -181,22 +189,27 @@ __global__ __launch_bounds__(512, 2) void gemm_ring_kernel(GemmParams P) {
     auto issue_one = [&](int64_t k0, int slot, int q) {
         char* st = smem + slot * RING_STAGE;   // (slot < RING_NS)
         if (q < 2) {
-            const bf16* src;
+            uint32_t vo;
+            int so;
             if constexpr (!CONV) {
-                src = a_src[q] + k0;
+                vo = a_vo[q];
+                so = (int)(k0 * 2);
             } else {
                 const int kh = ctap / P.cv.KW, kw = ctap - kh * P.cv.KW;
                 const bool ok = (cdma.tapmask[q] >> ctap) & 1u;
                 if constexpr (SHIFT) {
                     const int ih = ((int)(cdma.org[q] >> 16) - 2 + kh) >> 1, iw = ((int)(cdma.org[q] & 0xffffu) - 2 + kw) >> 1;
-                    src = ok ? P.A + cdma.pix_off[q] + (int64_t)((ih * P.cv.W + iw) * P.cv.C + cci + a_chunk[q]) : g_zero_page;
+                    vo = ok ? a_vo[q] + (uint32_t)((ih * P.cv.W + iw) * P.cv.C * 2) : kOob;
+                    so = cci * 2;
                 } else {
-                    src = ok ? P.A + cdma.pix_off[q] + (int64_t)((kh * P.cv.W + kw) * P.cv.C + cci + a_chunk[q]) : g_zero_page;
+                    vo = ok ? a_vo[q] : kOob;
+                    so = ((kh * P.cv.W + kw) * P.cv.C + cci) * 2;   // wave-uniform: the tap and the first channel of the K tile
                 }
             }
-            GLDS16(src, st + (wave * 2 + q) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * 2 + q) * 1024), 16, (int)vo, so, 0, 0);
         } else {
-            GLDS16(b_src[q - 2] + k0, st + RING_TILE + (wave * 2 + (q - 2)) * 1024);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + RING_TILE + (wave * 2 + (q - 2)) * 1024), 16,
+                                                     (int)b_vo[q - 2], (int)(k0 * 2), 0, 0);
         }
     };
     auto conv_advance = [&]() {

@@ -39,6 +39,10 @@ struct GemmParams {
     int sk_w;        //                K tiles per tail block
     int* counters;   // split-K: one arrival counter per output tile (zero on entry, left zero): the last K slice reduces in-kernel
     ConvGeom cv;
+    // fused SwiGLU epilogues of the pipelined 256 x 256 kernel (gemm.hip: EPI_SWIGLU_FWD / EPI_SWIGLU_BWD); glu_F = F (hidden width of the MLP)
+    const bf16* aux_in;   // BWD: the forward's packed [M, 2F] gate|up buffer
+    bf16* aux_out;        // FWD: act [M, F] = silu(gate) * up
+    int64_t ld_aux_in, ld_aux_out, glu_F;
 };
 
 namespace {
@@ -50,6 +54,9 @@ constexpr int B_K = 0, B_N = 1;
 
 constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
 constexpr int EPI_GEGLU = 4;  // gemm_ring.hip only: out[M, F] = (x Wh^T + bh) * gelu(x Wg^T + bg), weight rows [hidden F | gate F]
+// gemm.hip, pipelined 256 x 256 kernel only (DreamLLMMLP, modeling_dreamllm.py:237: down(silu(gate(x)) * up(x))):
+constexpr int EPI_SWIGLU_FWD = 5;  // C = [M, 2F] gate|up (as the plain GEMM) AND aux_out = silu(gate) * up, one launch
+constexpr int EPI_SWIGLU_BWD = 6;  // the down projection's input gradient d_act = dy Wd never leaves the block: C = [M, 2F] d(gate|up)
 
 // ---- LDS images -------------------------------------------------------------------------------------------------
 // k-contiguous tile: [128 rows][64 k] bf16, 128 B per row, 16-B chunk c stored at chunk c ^ ((row >> 1) & 7):

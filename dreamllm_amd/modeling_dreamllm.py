@@ -205,7 +205,11 @@ class _DecoderLayerFn(torch.autograd.Function):
         h2, _, rstd2 = ops.rmsnorm_fwd(x2, w_post, eps)
         F_ = wg.shape[0]
         wgu = _packed_view(wg, wu)
-        if wgu is not None:
+        y = act = None
+        fused = ops.linear_swiglu_fwd(h2.view(T, Hd), wgu) if wgu is not None else None   # gate|up GEMM with the SwiGLU in its epilogue
+        if fused is not None:
+            gu, act = fused
+        elif wgu is not None:
             gu = ops.linear_fwd(h2, wgu).view(T, 2 * F_)
         else:
             gu = torch.empty(T, 2 * F_, dtype=x.dtype, device=x.device)
@@ -214,8 +218,7 @@ class _DecoderLayerFn(torch.autograd.Function):
             ops.gemm(h22, wu, T, F_, Hd, Hd, Hd, 0, 0, out=gu[:, F_:])
         h2_keep = h2 if (keep and (ng[7] or ng[8])) else None
         del h2
-        y = act = None
-        if want_y or (keep and ng[9]):
+        if act is None and (want_y or (keep and ng[9])):
             act = ops.glu_fwd(gu[:, :F_], gu[:, F_:], 0)
         if want_y:
             y = ops.linear_fwd(act.view(B, S, F_), wd, residual=x2)
@@ -267,15 +270,19 @@ class _DecoderLayerFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dy = dy.contiguous()
         # ---- MLP
-        d_act = ops.linear_dgrad(dy, wd)
         g, u = gu[:, :F_], gu[:, F_:]
-        dgu = torch.empty_like(gu)
         act = act_keep
-        if act is None and need[9]:
-            act = torch.empty(T, F_, dtype=x.dtype, device=x.device)
-        # dg, du (AND, when it was not kept, the recomputed product) in one pass
-        ops.glu_bwd(d_act, g, u, 0, da=dgu[:, :F_], db=dgu[:, F_:], act_out=None if act_keep is not None else act)
-        del d_act
+        # d(gate|up) straight out of the down projection's input-gradient GEMM (SwiGLU backward in its epilogue) whenever the product
+        # itself need not be recomputed beside it
+        dgu = ops.linear_dgrad_swiglu(dy.view(T, Hd), wd, gu) if (act_keep is not None or not need[9]) else None
+        if dgu is None:
+            d_act = ops.linear_dgrad(dy, wd)
+            dgu = torch.empty_like(gu)
+            if act is None and need[9]:
+                act = torch.empty(T, F_, dtype=x.dtype, device=x.device)
+            # dg, du (AND, when it was not kept, the recomputed product) in one pass
+            ops.glu_bwd(d_act, g, u, 0, da=dgu[:, :F_], db=dgu[:, F_:], act_out=None if act_keep is not None else act)
+            del d_act
         dwd = None
         if need[9]:
             dwd = ops.linear_wgrad(dy, act)

@@ -400,6 +400,56 @@ def linear_geglu(x, w, bias=None):
     return y.view(*x.shape[:-1], F_)
 
 
+# Fused SwiGLU epilogues of the MLP's two large GEMMs (round 6; csrc/gemm.hip gemm_epilogue_swiglu_*): same results as the unfused
+# launches, one launch and one HBM round trip of an [M, F] / [M, 2F] tensor fewer each.  DREAMLLM_FUSED_SWIGLU=0 is the A/B knob.
+FUSED_SWIGLU = os.environ.get("DREAMLLM_FUSED_SWIGLU", "1") != "0"
+
+
+def _glu_group_m(layout, M, N, K):
+    return _GROUP_M_TABLE.get((layout[0], layout[1], M, N, K), 0)
+
+
+def linear_swiglu_fwd(x, wgu):
+    """(gu, act) = (x wgu^T, silu(gu[:, :F]) * gu[:, F:]) in ONE launch; x [M, K], wgu [2F, K] = packed [gate rows; up rows].
+    Returns None for shapes the fused kernel does not take (the caller runs GEMM + glu_fwd)."""
+    if not FUSED_SWIGLU or (GEMM_VARIANT & 0xffff) not in (0, 259):
+        return None
+    x2 = _as2d(x)
+    M, K = x2.shape
+    F2 = wgu.shape[0]
+    F_ = F2 // 2
+    if M % 256 or F_ % 128 or K % 64 or K < 64 or not wgu.is_contiguous():
+        return None
+    _need_gpu(x2, wgu)
+    _bf16(x2, wgu)
+    gu = torch.empty(M, F2, dtype=x.dtype, device=x.device)
+    act = torch.empty(M, F_, dtype=x.dtype, device=x.device)
+    with _GemmTimer(2.0 * M * F2 * K, _GEMM_TAG[(0, 0)]):
+        check("dllm_gemm_swiglu_fwd", _p(x2), _p(wgu), _p(gu), _p(act), M, F_, K, x2.stride(0), K, F2, F_,
+              _glu_group_m((0, 0), M, F2, K), _stream())
+    return gu, act
+
+
+def linear_dgrad_swiglu(dy, wd, gu, dgu=None):
+    """d(gate|up) [M, 2F] of act = silu(gate) * up, given dy [M, D] of the down projection (weight wd [D, F]) and the forward's packed
+    gate|up buffer: the input gradient d_act = dy wd never leaves the GEMM.  None for shapes the fused kernel does not take."""
+    if not FUSED_SWIGLU or (GEMM_VARIANT & 0xffff) not in (0, 259):
+        return None
+    d2 = _as2d(dy)
+    M, D = d2.shape
+    F_ = wd.shape[1]
+    if M % 256 or F_ % 256 or D % 64 or D < 64 or not wd.is_contiguous() or gu.shape != (M, 2 * F_) or gu.stride(1) != 1 or gu.stride(0) % 8:
+        return None
+    _need_gpu(d2, wd, gu)
+    _bf16(d2, wd, gu)
+    if dgu is None:
+        dgu = torch.empty(M, 2 * F_, dtype=gu.dtype, device=gu.device)
+    with _GemmTimer(2.0 * M * F_ * D, _GEMM_TAG[(0, 1)]):
+        check("dllm_gemm_swiglu_bwd", _p(d2), _p(wd), _p(gu), _p(dgu), M, F_, D, d2.stride(0), F_, gu.stride(0), dgu.stride(0),
+              _glu_group_m((0, 1), M, F_, D), _stream())
+    return dgu
+
+
 def linear_dgrad(dy, w):
     """dx = dy W ; dy [..., N], w [N, K]."""
     d2 = _as2d(dy)

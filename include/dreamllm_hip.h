@@ -118,6 +118,18 @@ int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bia
                           int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int64_t ldr, int layout_a, int layout_b, int epi,
                           int out_dtype, int accumulate, float alpha, int splitk, float* workspace, int* counters, int variant,
                           void* stream);
+/* DreamLLMMLP.forward, modeling_dreamllm.py:237 `down_proj(act_fn(gate_proj(x)) * up_proj(x))`, with the SwiGLU folded into the GEMMs
+ * beside it (SURVEY §8(b2) `silu_mul` epilogue; round 6).  wgu = the packed [2F, K] weight (gate rows, then up rows).
+ *   fwd: gu[M, 2F] = x wgu^T  AND  act[M, F] = silu(gu[:, :F]) * gu[:, F:]  in one launch (replaces GEMM + dllm_glu_fwd);
+ *   bwd: dgu[M, 2F] = d(gate|up) of the product given dy [M, D] and the down projection's weight wd [D, F]: d_act = dy wd stays in the
+ *        accumulators (replaces the input-gradient GEMM + dllm_glu_bwd).
+ * Same arithmetic on the same bf16-rounded operands as the unfused pair: identical results.  M % 256 == 0, K / D % 64 == 0,
+ * F % 128 == 0 (fwd) / F % 256 == 0 (bwd), 16-byte aligned pointers, leading dimensions % 8 == 0; otherwise DLLM_ERR_SHAPE / _ALIGN and
+ * the caller uses the unfused launches.  group_m: GROUP_M of the grouped tile order (0 = default). */
+int dllm_gemm_swiglu_fwd(const void* x, const void* wgu, void* gu, void* act, int64_t M, int64_t F, int64_t K, int64_t ldx, int64_t ldw,
+                         int64_t ldgu, int64_t ldact, int group_m, void* stream);
+int dllm_gemm_swiglu_bwd(const void* dy, const void* wd, const void* gu, void* dgu, int64_t M, int64_t F, int64_t D, int64_t lddy,
+                         int64_t ldw, int64_t ldgu, int64_t lddgu, int group_m, void* stream);
 int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
                                  const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                                  int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,

@@ -1088,3 +1088,63 @@ def test_wide_head_attention_and_row_softmax(N, Sq, Sk, C):
     x = torch.randn(37, 1003, device=DEV) * 3
     x4 = torch.nn.functional.pad(x, (0, 1))[:, :1004]  # pitch multiple of 4
     assert rel_l2(ops.softmax_rows(x4[:, :1000].contiguous()), torch.softmax(x4[:, :1000].float(), -1).cpu()) < 4e-3
+
+
+# ----------------------------------------------------------------------------- fused SwiGLU epilogues (round 6)
+@pytest.mark.parametrize("M,F_,K", [(256, 256, 64), (512, 512, 256), (1024, 768, 320), (256, 1280, 4096), (8192, 2816, 1024)])
+def test_gemm_swiglu_fwd_equals_gemm_plus_glu(M, F_, K):
+    """gate|up projection with the SwiGLU in its epilogue (dllm_gemm_swiglu_fwd) == the GEMM followed by dllm_glu_fwd: the product is
+    bit for bit what dllm_glu_fwd makes of the packed gate|up tile the same launch stored; that tile equals the plain GEMM's output bit
+    for bit wherever the plain GEMM runs on the same kernel (small grids take other families: another summation order over K) and the
+    fp32 oracle to bf16 rounding everywhere."""
+    ops = _ops()
+    torch.manual_seed(M + F_ + K)
+    x, w = rnd(M, K).to(DEV), rnd(2 * F_, K, scale=K ** -0.5).to(DEV)
+    out = ops.linear_swiglu_fwd(x, w)
+    assert out is not None
+    gu, act = out
+    assert torch.equal(act, ops.glu_fwd(gu[:, :F_], gu[:, F_:], 0))
+    ref = x.float().cpu() @ w.float().cpu().t()
+    assert rel_l2(gu, ref) < 4e-3
+    assert rel_l2(act, F.silu(ref[:, :F_]) * ref[:, F_:]) < 8e-3   # two bf16 roundings (gate|up, then the product)
+    with ops.gemm_variant(259):
+        gu0 = ops.linear_fwd(x, w)
+    if (M // 256) * (2 * F_ // 256) >= 128 or K <= 320:   # grids on which variant 259 keeps the 256 x 256 pipelined kernel
+        assert torch.equal(gu, gu0)
+    else:
+        assert rel_l2(gu, gu0.float()) < 2e-3
+
+
+@pytest.mark.parametrize("M,F_,D", [(256, 256, 64), (512, 512, 256), (768, 1024, 320), (256, 256, 4096)])
+def test_gemm_swiglu_bwd_equals_dgrad_plus_glu_bwd(M, F_, D):
+    """the down projection's input gradient with the SwiGLU backward in its epilogue (dllm_gemm_swiglu_bwd) == dgrad GEMM + dllm_glu_bwd,
+    bit for bit; and against fp32 autograd."""
+    ops = _ops()
+    torch.manual_seed(M + F_ + D + 1)
+    dy, wd, gu = rnd(M, D).to(DEV), rnd(D, F_, scale=D ** -0.5).to(DEV), rnd(M, 2 * F_).to(DEV)
+    dgu = ops.linear_dgrad_swiglu(dy, wd, gu)
+    assert dgu is not None
+    with ops.gemm_variant(259):
+        d_act = ops.linear_dgrad(dy, wd)
+    dgu0 = torch.empty_like(gu)
+    ops.glu_bwd(d_act, gu[:, :F_], gu[:, F_:], 0, da=dgu0[:, :F_], db=dgu0[:, F_:])
+    if D <= 320:      # (deep reductions on tiny grids: the unfused GEMM takes another kernel family, see the forward test)
+        assert torch.equal(dgu, dgu0)
+    else:
+        assert rel_l2(dgu, dgu0.float()) < 4e-3
+    gr = gu.float().cpu().requires_grad_(True)
+    act = F.silu(gr[:, :F_]) * gr[:, F_:]
+    act.backward(dy.float().cpu() @ wd.float().cpu())
+    assert rel_l2(dgu, gr.grad) < 8e-3
+
+
+def test_gemm_swiglu_rejects_what_it_does_not_take():
+    ops = _ops()
+    x = rnd(200, 64).to(DEV)          # M % 256 != 0: the wrappers decline (the caller runs the unfused launches) ...
+    assert ops.linear_swiglu_fwd(x, rnd(256, 64).to(DEV)) is None
+    assert ops.linear_dgrad_swiglu(rnd(256, 64).to(DEV), rnd(64, 128).to(DEV), rnd(256, 256).to(DEV)) is None   # F % 256 != 0
+    from dreamllm_amd import _lib     # ... and the C entry points refuse instead of touching memory
+    import ctypes
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    a, w, g, o = rnd(200, 64).to(DEV), rnd(256, 64).to(DEV), torch.empty(200, 256, dtype=BF, device=DEV), torch.empty(200, 128, dtype=BF, device=DEV)
+    assert _lib.call("dllm_gemm_swiglu_fwd", p(a), p(w), p(g), p(o), 200, 128, 64, 64, 64, 256, 128, 0, None) == -1
