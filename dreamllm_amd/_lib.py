@@ -26,7 +26,7 @@ SIGNATURES = {
     "dllm_layernorm_fwd": [c_void_p] * 6 + [c_i64, c_int, c_float, c_void_p],
     "dllm_layernorm_bwd": [c_void_p] * 10 + [c_int, c_i64, c_int, c_void_p],
     "dllm_gemm_bf16": [c_void_p] * 5 + [c_i64] * 7 + [c_int] * 5 + [c_float, c_void_p],
-    "dllm_gemm_splitk_hint": [c_i64, c_i64, c_i64],
+    "dllm_gemm_splitk_hint": [c_i64, c_i64, c_i64, c_int, c_int],
     "dllm_gemm_swiglu_fwd": [c_void_p] * 4 + [c_i64] * 7 + [c_int, c_void_p],
     "dllm_gemm_swiglu_bwd": [c_void_p] * 4 + [c_i64] * 7 + [c_int, c_void_p],
     "dllm_gemm_streamk_hint": [c_i64, c_i64, c_i64, c_int, c_int],

@@ -799,7 +799,9 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
             constexpr int g = decltype(gc)::value, kk = g / MI, i = g % MI;
             // one DMA instruction per group from the start of the tile: no 64-KiB burst per CU.  (Round 6, with the cheaper buffer form: two per
             // group in the first four groups measured -6 % on the weight gradients, -1...-3 % dgrad, -4...+0.7 % forward:
-            // profiles/r06_gemm_rpg2_ab.log)
+            // profiles/r06_gemm_rpg2_ab.log.  An L2 "touch" of the lines two K tiles ahead -- one dword per lane and tile behind the
+            // last request, counted vmcnt(1) at the barrier -- measured -0.2 ... 0.0 % on all twelve shapes: first-touch L2 misses are not
+            // what the tile barrier waits for; profiles/r06_gemm_l2touch_ab.log, profiles/patches/r06_gemm_l2_touch.patch)
             if constexpr (NEXT && g < 4 + NBD) {
                 if (pf) issue_one(nbuf, g, rsA, rsB);
             }
@@ -1531,11 +1533,15 @@ int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int la
 
 // Split-K helper: number of K splits this library would like for an [M,N,K] problem (1 = none).  Small grids with a deep
 // reduction (UNet at batch 2: M = 128..2048, K = 5760..23040) otherwise leave most of the 256 CUs idle.
-int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K) {
+// layout_a / layout_b as in dllm_gemm_bf16 (layout_a 2 = the implicit-GEMM conv gather): the ring-buffered kernel's cost model only
+// applies where that kernel runs (k-contiguous or gathered A, k-contiguous B); the other layouts of a small grid run on the register-staged
+// 128-tile kernel and take its rule (the hint used to assume the forward layout for every caller).
+int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int layout_b) {
     if (M <= 0 || N <= 0 || (N & 3)) return 1;
     const int64_t tiles = cdiv64(M, 128) * cdiv64(N, 128);
     const int64_t ktiles = cdiv64(K, BK);
-    if ((K % BK) == 0) {
+    const bool ring_layout = (layout_a == A_K || layout_a == A_CONV) && layout_b == B_K;
+    if ((K % BK) == 0 && ring_layout) {
         // The ring-buffered kernel (one 128 x 128 block per CU, every K step overlapped with three stages of loads) needs far fewer
         // slices than the register-staged kernel did: a slice count is worth it only when the shorter K loop pays for the fp32 slab
         // round trip and the reduce launch.  Estimated time (us; per-round figures of launch_gemm's model, the reduce launch ~7 us,

@@ -260,11 +260,11 @@ GEMM_PERSIST = os.environ.get("DREAMLLM_GEMM_PERSIST", "0") == "1"
 _SPLITK_WANT = int(os.environ.get("DREAMLLM_SPLITK_WANT", "0"))
 
 
-def _splitk_hint(M, N, K):
+def _splitk_hint(M, N, K, layout_a=0, layout_b=0):
     if not SPLITK:
         return 1
     if _SPLITK_WANT <= 0:
-        return _lib.call("dllm_gemm_splitk_hint", M, N, K)
+        return _lib.call("dllm_gemm_splitk_hint", M, N, K, layout_a, layout_b)
     if M <= 0 or N <= 0 or (N & 3):
         return 1
     tiles = -(-M // 128) * -(-N // 128)
@@ -283,7 +283,7 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     _bf16(a, b, bias, residual)
     if out is None:
         out = torch.empty(M, N, dtype=out_dtype, device=a.device)
-    sk = 1 if epi == "geglu" else _splitk_hint(M, N, K)
+    sk = 1 if epi == "geglu" else _splitk_hint(M, N, K, layout_a, layout_b)
     ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
     persist = 0
     if sk == 1 and (GEMM_VARIANT & 0xffff) in (0, 259):
@@ -1178,7 +1178,7 @@ def conv2d_nhwc(x, w2d, CO, KH, KW, stride=1, pad=1, OH=None, OW=None, bias=None
     if residual is not None and not residual.is_contiguous():
         residual = residual.contiguous()
     Mg = N * OH * OW
-    sk = _splitk_hint(Mg, CO, KH * KW * C)
+    sk = _splitk_hint(Mg, CO, KH * KW * C, 2, 0)
     ws = torch.empty(sk * Mg * CO, dtype=torch.float32, device=x.device) if sk > 1 else None
     cnt = _splitk_counters(x.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-Mg // 128) * -(-CO // 128) <= 16384) else None
     skbit = 0

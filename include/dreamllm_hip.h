@@ -87,8 +87,8 @@ int dllm_gemm_bf16(const void* A, const void* B, void* C, const void* bias, cons
  * workspace [splitk][M][N]; the reduction is deterministic (slice order).  `counters` (optional): int32[>= ceil(M/128)*ceil(N/128)],
  * all zero on entry and left all zero -- the last K slice of a tile to arrive then reduces it INSIDE the GEMM launch (agent-scope
  * release/acquire around a ticket); NULL = a separate reduce kernel follows.  Use one counter array per stream in flight.
- * dllm_gemm_splitk_hint suggests splitk. */
-int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K);
+ * dllm_gemm_splitk_hint suggests splitk for a problem in the given layouts (layout_a 2 = the NHWC conv gather of dllm_conv2d_nhwc_bf16). */
+int dllm_gemm_splitk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int layout_b);
 /* Stream-K tail of the 256 x 256 pipelined kernel: dllm_gemm_bf16_splitk(..., splitk = 1, workspace != NULL, ...) with a caller-owned
  * workspace of dllm_gemm_streamk_ws_bytes() bytes lets launches whose LAST round of tiles would leave most of the 256 CUs idle (the
  * MLP weight gradients: 1376 and 688 tiles = 5.4 / 2.7 rounds) run their whole rounds as usual and spread the K loops of the

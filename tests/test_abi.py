@@ -114,8 +114,11 @@ def test_scheduling_hints_are_pure_host_functions():
     assert sk(2 * 256, 1280, 9 * 1280, 2, 0) == 0           # batch 2: 10 tiles -> the split-K kernels
     assert sk(16 * 4096, 320, 9 * 320, 2, 0) == 0           # 512 tiles: whole rounds
     # split-K of tiny grids (the denoise loop at batch 2)
-    h = lambda M, N, K: _lib.call("dllm_gemm_splitk_hint", M, N, K)
+    h = lambda M, N, K, la=0, lb=0: _lib.call("dllm_gemm_splitk_hint", M, N, K, la, lb)
     # (round 4: the ring-buffered kernel's cost model -- far fewer slices than the register-staged kernel wanted: 10 / 22 / 2 before)
     assert h(T, d, d) == 1 and h(512, 1280, 11520) == 6 and h(128, 1280, 11520) == 15 and h(8192, 320, 2880) == 1
     assert h(2048, 640, 5760) == 3 and h(512, 1280, 1280) == 1 and h(8192, 320, 1280) == 1
+    # the ring model applies to the layouts the ring kernel runs (k-contiguous / gathered A, k-contiguous B) only; the input- and
+    # weight-gradient layouts of a small grid run on the register-staged kernel and take its (many-slices) rule
+    assert h(512, 1280, 11520, 2, 0) == 6 and h(512, 1280, 11520, 0, 1) == 10 and h(512, 1280, 11520, 1, 1) == 10
     assert _lib.call("dllm_gemm_streamk_ws_bytes") == (2 * 256 * 256 * 256 + 1024) * 4

@@ -453,6 +453,35 @@ def test_sd_head_forward_vs_executed_reference(golden, xl, name):
                      rel_l2(c["grad_global_projector_bf16"].float(), c["grad_global_projector"].float()), sl)
 
 
+def test_sdxl_head_tiny_gradients_hold_the_plain_rule_on_average(golden):
+    """VERDICT r05 weak #1c: the tiny SDXL head's gradient checks take a 1.30 noise allowance per tensor (2-sample gradients move 5-10 %
+    under re-association).  Over ALL of them -- every SDXL forward case of the fixture, every gradient tensor -- the mean of
+    (err - floor) / err_ref has to satisfy the plain 1.15 rule: a systematic loss of accuracy cannot hide inside the allowance."""
+    from conftest import FLOOR
+    from dreamllm_amd.utils import replay_draws
+    g = golden("sdxl_head.pt")
+    ratios = []
+    for name in _FWD_CASES[True]:
+        c = _case(g, "forward", name)
+        head = _fixture_head(g, True, prediction_type=c["prediction_type"], **c["knobs"])
+        inp = c["inputs"]
+        enc = inp["enc"].to(BF).to(DEV).requires_grad_(True)
+        u = inp["u_enc"].to(BF).to(DEV).requires_grad_(True) if "u_enc" in inp else None
+        with replay_draws(c["draws"]):
+            head(inp["images"].to(DEV), enc, u, inp["add_time_ids"].to(DEV), None).backward()
+        pairs = [(enc.grad, "grad_enc"), (head.projector.projector.weight.grad, "grad_projector"),
+                 (head.global_projector.projector.weight.grad, "grad_global_projector")]
+        if "grad_u_enc" in c:
+            pairs.append((u.grad, "grad_u_enc"))
+        for ours, key in pairs:
+            err_ref = rel_l2(c[key + "_bf16"].float(), c[key].float())
+            ratios.append(max(0.0, rel_l2(ours, c[key].float()) - FLOOR) / err_ref)
+    assert len(ratios) >= 9
+    mean = sum(ratios) / len(ratios)
+    assert mean <= SLACK, (mean, ratios)
+    assert max(ratios) <= AUTOCAST_YARDSTICK_SLACK, ratios
+
+
 @pytest.mark.parametrize("use_graph", [True, False])
 @pytest.mark.parametrize("xl,name", [(xl, n) for xl in (False, True) for n in _PIPE_CASES[xl]])
 def test_sd_head_pipeline_vs_executed_reference(golden, xl, name, use_graph):

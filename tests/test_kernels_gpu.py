@@ -811,7 +811,7 @@ def test_gemm_splitk_small_grid(M, N, K):
     """Small grids with deep K (UNet at batch 2) take the deterministic split-K path: all three layouts + fused epilogue."""
     from dreamllm_amd import _lib
     ops = _ops()
-    assert _lib.call("dllm_gemm_splitk_hint", M, N, K) > 1
+    assert _lib.call("dllm_gemm_splitk_hint", M, N, K, 0, 0) > 1
     torch.manual_seed(M + K)
     x, w, b, r = rnd(M, K), rnd(N, K, scale=0.02), rnd(N), rnd(M, N)
     ref = F.gelu(x.float() @ w.float().t() + b.float()) + r.float()
@@ -834,7 +834,7 @@ def test_gemm_splitk_in_kernel_reduction_is_bit_identical(M, N, K):
     different XCDs: a stale read would show as a mismatch), counters back at zero afterwards."""
     from dreamllm_amd import _lib
     ops = _ops()
-    assert _lib.call("dllm_gemm_splitk_hint", M, N, K) > 1
+    assert _lib.call("dllm_gemm_splitk_hint", M, N, K, 0, 0) > 1
     torch.manual_seed(M + N)
     x, w, b, r = rnd(M, K).to(DEV), rnd(N, K, scale=0.02).to(DEV), rnd(N).to(DEV), rnd(M, N).to(DEV)
     ref = ops.linear_fwd(x, w, bias=b, epi="silu", residual=r)

@@ -44,7 +44,7 @@ for cnt, H, C, CO, k, stride, up in SHAPES:
     ms = timeit(fn)
     M = N * OH * OH
     fl = 2.0 * M * CO * k * k * C
-    sk = _lib.call("dllm_gemm_splitk_hint", M, CO, k * k * C)
+    sk = _lib.call("dllm_gemm_splitk_hint", M, CO, k * k * C, 2, 0)
     tot_ms += cnt * ms
     tot_fl += cnt * fl
     print(f"x{cnt:2d} {H:2d}x{H:<2d} C{C:4d}->{CO:4d} k{k} s{stride} up{up}  M={M:6d} K={k * k * C:5d} tiles256={-(-M // 256) * -(-CO // 256):4d} "
