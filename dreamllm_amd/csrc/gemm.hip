@@ -42,11 +42,12 @@ struct Variant {
     int no_ring = 0;     // bit 25: never pick the ring-buffered kernel by itself (the round-3 selection: A/B knob of tools / bench)
     int dma_mode = -1;     // bench builds: tile codes 271-276, placement of the ring kernel's LDS-DMA requests (experiment)
     int force_mfma32 = 0;  // tile code 266: the MFMA 32x32x16 experiment (gemm_mfma32.hip) wherever it is eligible (tools)
+    int force_w4 = 0;      // tile code 261: the four-wave experiment (gemm_w4.hip) wherever it is eligible (tools)
 };
 static inline int parse_variant(int variant, Variant& v) {
     const int tile = variant & 0xffff;
     v.group_m = (variant >> 16) & 0xff;
-    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 262 || tile == 264 || tile == 266 || tile == 267 || tile == 268;
+    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 261 || tile == 262 || tile == 264 || tile == 266 || tile == 267 || tile == 268;
 #ifdef DLLM_BENCH_MODES
     ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265 || (tile >= 269 && tile <= 279);
     v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : ((tile >= 269 && tile <= 279) ? 4 : 0)));
@@ -68,6 +69,7 @@ static inline int parse_variant(int variant, Variant& v) {
     if (tile == 267 || tile == 268 || (tile >= 269 && tile <= 279)) v.ring_stages = (tile == 267 || tile == 269 || (tile >= 271 && tile <= 273) || tile >= 277) ? -1 : 1;
     v.dma_mode = (tile >= 271 && tile <= 273) ? tile - 270 : ((tile >= 274 && tile <= 276) ? tile - 273 : ((tile == 277 || tile == 278) ? tile - 273 : (tile == 279 ? 0 : -1)));   // -1: the kernel's default; 279: two-stage with one request per MFMA group   // 277: no LDS-DMA in the loop, 278: no MFMAs (ablations, two-stage flag ignored: four-stage)
     v.force_mfma32 = tile == 266;
+    v.force_w4 = tile == 261;
     if (v.force_ring) v.force_tile = 0;
     return DLLM_OK;
 }
@@ -1269,10 +1271,10 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
         return dllm_launch_gemm_ring(Q, AL, stream, V.ring_stages);
     }
     if constexpr (AL == A_K && BL == B_K) {
-        if (V.force_mfma32 && (P.M % 256) == 0 && (P.N % 256) == 0 && (P.K % BK) == 0 && P.K >= BK && !P.out_f32 && P.bias == nullptr &&
+        if ((V.force_mfma32 || V.force_w4) && (P.M % 256) == 0 && (P.N % 256) == 0 && (P.K % BK) == 0 && P.K >= BK && !P.out_f32 && P.bias == nullptr &&
             P.residual == nullptr && P.rg_bias == nullptr && P.epi == 0 && !P.accumulate && P.splitk <= 1 && (P.ldc & 7) == 0 &&
             (reinterpret_cast<uintptr_t>(P.C) & 15) == 0)
-            return dllm_launch_gemm_pipe32(P, stream);
+            return V.force_w4 ? dllm_launch_gemm_w4(P, stream) : dllm_launch_gemm_pipe32(P, stream);
     }
     ring = ring && V.force_tile == 0 && !V.no_ring;   // tile codes 128 / 256 / 257 / 259 keep selecting the older families (tests)
     const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);

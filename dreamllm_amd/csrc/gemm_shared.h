@@ -449,3 +449,5 @@ __device__ __attribute__((aligned(16))) bf16 g_zero_page[8];
 __attribute__((visibility("hidden"))) int dllm_launch_gemm_ring(const GemmParams& P, int layout_a, hipStream_t stream, int two_stage = 0);
 // gemm_mfma32.hip (experiment): the 256 x 256 pipelined kernel on v_mfma_f32_32x32x16_bf16; forward layout, full tiles, plain epilogue
 __attribute__((visibility("hidden"))) int dllm_launch_gemm_pipe32(const GemmParams& P, hipStream_t stream);
+// gemm_w4.hip (round 6 experiment): four waves, one per SIMD, wave tile 128 x 128 on MFMA 32x32x16, buffer-form LDS-DMA; same eligibility
+__attribute__((visibility("hidden"))) int dllm_launch_gemm_w4(const GemmParams& P, hipStream_t stream);

@@ -139,7 +139,7 @@ def test_layernorm_fwd_bwd(rows, D):
 
 
 # ----------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[128, 256, 257, 259, 262, 264, 266])
+@pytest.fixture(params=[128, 256, 257, 259, 261, 262, 264, 266])
 def gemm_tile(request):
     """run the GEMM tests once per block-tile variant (128x128 / 4 waves and 256x256 / 8 waves)"""
     from dreamllm_amd import ops
@@ -1148,3 +1148,21 @@ def test_gemm_swiglu_rejects_what_it_does_not_take():
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     a, w, g, o = rnd(200, 64).to(DEV), rnd(256, 64).to(DEV), torch.empty(200, 256, dtype=BF, device=DEV), torch.empty(200, 128, dtype=BF, device=DEV)
     assert _lib.call("dllm_gemm_swiglu_fwd", p(a), p(w), p(g), p(o), 200, 128, 64, 64, 64, 256, 128, 0, None) == -1
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (1024, 512, 4096), (2048, 2304, 1024)])
+def test_gemm_w4_experiment(M, N, K):
+    """tile code 261: the four-wave 256 x 256 kernel of round 6 (one wave per SIMD, MFMA 32x32x16, buffer-form LDS-DMA; csrc/gemm_w4.hip)
+    against the fp32 oracle, on one, two, three and many K tiles (prologue / steady state / the two peeled tail bodies)."""
+    ops = _ops()
+    torch.manual_seed(M + N + K)
+    x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
+    ref = x.float() @ w.float().t()
+    with ops.gemm_variant(261):
+        y = ops.linear_fwd(x.to(DEV), w.to(DEV))
+        y2 = ops.linear_fwd(x.to(DEV), w.to(DEV))
+    assert rel_l2(y, ref) < 4e-3
+    assert torch.equal(y, y2)
+    with ops.gemm_variant(259):
+        y0 = ops.linear_fwd(x.to(DEV), w.to(DEV))
+    assert rel_l2(y, y0.float()) < 3e-3

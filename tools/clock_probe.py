@@ -1,4 +1,4 @@
-"""Sustained clocks / power while one kernel family runs back to back: python tools/clock_probe.py {attn_bwd,attn_fwd,gemm,idle}
+"""Sustained clocks / power while one kernel family runs back to back: python tools/clock_probe.py {attn_bwd,attn_fwd,gemm,gemm259,gemm261,idle}
 Polls rocm-smi once per second from a thread while the main thread keeps the GPU busy for ~6 s."""
 import os
 import subprocess
@@ -18,6 +18,7 @@ q, k, v, do = (torch.randn(B, S, H, D, device="cuda").to(BF) for _ in range(4))
 o, lse = ops.attn_fwd(q, k, v, True)
 a = torch.randn(32768, 4096, device="cuda").to(BF)
 w = torch.randn(11008, 4096, device="cuda").to(BF)
+w2 = torch.randn(22016, 4096, device="cuda").to(BF) if what.startswith("gemm2") else None
 stop = False
 samples = []
 
@@ -42,6 +43,9 @@ while time.time() - t0 < 6.0:
             ops.attn_fwd(q, k, v, True)
         elif what == "gemm":
             ops.linear_fwd(a, w)
+        elif what.startswith("gemm"):     # gemm259 / gemm261: one kernel family (tile code) on the packed gate|up forward shape
+            with ops.gemm_variant(int(what[4:])):
+                ops.linear_fwd(a, w2)
         else:
             time.sleep(0.01)
     torch.cuda.synchronize()
