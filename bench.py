@@ -288,7 +288,7 @@ def main():
                     achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(tf / PEAK_BF16_TFLOPS, 4), traffic=None,
                     note="achieved = algorithmic 2*B_img*0.803 TFLOP per step / measured step time (whole loop body: the launches "
                          "live inside one hipGraph replay, so per-launch HIP events do not apply); kernel-level shares: "
-                         "profiles/r05_denoise_kernel_stats.csv (B_img 1), r05_denoise_b8_kernel_stats.csv (B_img 8)")))
+                         "profiles/r06_denoise_kernel_stats.csv (B_img 1), r06_denoise_b8_kernel_stats.csv (B_img 8)")))
         denoise = dict(legs[0], legs=legs) if legs else None
         if denoise is not None and not tiny:
             denoise["frac_mfma_peak"] = legs[0]["roofline"]["frac"]
