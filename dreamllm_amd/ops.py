@@ -424,7 +424,7 @@ def linear_swiglu_fwd(x, wgu):
     _bf16(x2, wgu)
     gu = torch.empty(M, F2, dtype=x.dtype, device=x.device)
     act = torch.empty(M, F_, dtype=x.dtype, device=x.device)
-    with _GemmTimer(2.0 * M * F2 * K, _GEMM_TAG[(0, 0)]):
+    with _GemmTimer(2.0 * M * F2 * K, "fwd_swiglu"):   # (its own line in bench.py's by_kind: the launch carries the SwiGLU's stores)
         check("dllm_gemm_swiglu_fwd", _p(x2), _p(wgu), _p(gu), _p(act), M, F_, K, x2.stride(0), K, F2, F_,
               _glu_group_m((0, 0), M, F2, K), _stream())
     return gu, act
@@ -444,7 +444,7 @@ def linear_dgrad_swiglu(dy, wd, gu, dgu=None):
     _bf16(d2, wd, gu)
     if dgu is None:
         dgu = torch.empty(M, 2 * F_, dtype=gu.dtype, device=gu.device)
-    with _GemmTimer(2.0 * M * F_ * D, _GEMM_TAG[(0, 1)]):
+    with _GemmTimer(2.0 * M * F_ * D, "dgrad_swiglu"):
         check("dllm_gemm_swiglu_bwd", _p(d2), _p(wd), _p(gu), _p(dgu), M, F_, D, d2.stride(0), F_, gu.stride(0), dgu.stride(0),
               _glu_group_m((0, 1), M, F_, D), _stream())
     return dgu
