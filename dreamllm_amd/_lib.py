@@ -29,6 +29,7 @@ SIGNATURES = {
     "dllm_gemm_splitk_hint": [c_i64, c_i64, c_i64, c_int, c_int],
     "dllm_gemm_swiglu_fwd": [c_void_p] * 4 + [c_i64] * 7 + [c_int, c_void_p],
     "dllm_gemm_swiglu_bwd": [c_void_p] * 4 + [c_i64] * 7 + [c_int, c_void_p],
+    "dllm_gemm_rope_qkv": [c_void_p] * 6 + [c_i64] * 4 + [c_int] + [c_i64] * 3 + [c_int, c_void_p],
     "dllm_gemm_streamk_hint": [c_i64, c_i64, c_i64, c_int, c_int],
     "dllm_gemm_bf16_splitk": [c_void_p] * 5 + [c_i64] * 7 + [c_int] * 5 + [c_float, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "dllm_conv2d_nhwc_bf16_splitk": [c_void_p] * 6 + [c_int] * 15 + [c_int, c_void_p, c_void_p, c_int, c_void_p],

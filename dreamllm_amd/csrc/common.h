@@ -81,6 +81,14 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
     return r;
 }
 
+// rotate_half pair of apply_rotary_pos_emb (modeling_dreamllm.py:176-209): y1 = x1 c - x2 s, y2 = x2 c + x1 s, in ONE fixed operation
+// order (a rounded product, then a fused multiply-add) so that every kernel that inlines it -- rope_kernel, the q|k|v GEMM's RoPE
+// epilogue -- produces the same bits (left to -ffast-math, the contraction differed between the two and one element in 2e5 moved an ulp)
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& y1, float& y2) {
+    const float t1 = x2 * s, t2 = x1 * s;
+    y1 = __builtin_fmaf(x1, c, -t1);
+    y2 = __builtin_fmaf(x2, c, t2);
+}
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

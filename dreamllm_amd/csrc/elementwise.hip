@@ -29,9 +29,10 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16* __restrict__ x, const f
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float cc = c[e], ss = s[e] * sign;
-            const float x1 = (float)a[e], x2 = (float)b[e];
-            o1[e] = (bf16)(x1 * cc - x2 * ss);
-            o2[e] = (bf16)(x2 * cc + x1 * ss);
+            float y1, y2;
+            rope_pair((float)a[e], (float)b[e], cc, ss, y1, y2);
+            o1[e] = (bf16)y1;
+            o2[e] = (bf16)y2;
         }
         st_bf16x8(p1, o1);
         st_bf16x8(p2, o2);

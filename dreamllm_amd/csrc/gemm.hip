@@ -683,8 +683,13 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
     // EPI_SWIGLU_FWD: the B tile's 256 rows are re-mapped so that every wave holds 32 gate columns and the 32 up columns of the SAME
     // outputs (tile row r of wave column block r >> 6: rows 0-31 = gate rows, 32-63 = the matching up rows F further down the packed
     // weight); block column pid_n then covers the outputs [n0 / 2, n0 / 2 + 128).  Free on the DMA's per-lane offset.
-    bool glu_map = false;
-    if constexpr (AL == A_K && BL == B_K && BN == 256) glu_map = P.epi == EPI_SWIGLU_FWD;
+    bool glu_map = false, rope_map = false;
+    if constexpr (AL == A_K && BL == B_K && BN == 256) {
+        glu_map = P.epi == EPI_SWIGLU_FWD;
+        // EPI_ROPE_QKV (head_dim 128: a tile = two heads): wave column block wc holds dims [32 (wc & 1), +32) of head wc >> 1 in its first 32
+        // columns and the partner dims 64 further in the other 32 -- rotate_half's pairs meet in one lane
+        rope_map = P.epi == EPI_ROPE_QKV && n0 < P.rope_cols;
+    }
 #pragma unroll
     for (int q = 0; q < NBD; ++q) {
         if constexpr (BL == B_K) {
@@ -693,6 +698,7 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
             const int c = (lane & 7) ^ ((r >> 1) & 7);
             int64_t rr = min((int64_t)r, P.N - 1 - n0);
             if (glu_map) rr = ((r & 32) ? P.glu_F : 0) + (r >> 6) * 32 + (r & 31);   // relative to weight row n0 / 2 (the descriptor origin below)
+            if (rope_map) rr = (r >> 7) * 128 + ((r >> 6) & 1) * 32 + (r & 31) + ((r & 32) ? 64 : 0);
             voB[q] = (uint32_t)((rr * P.ldb + c * 8) * 2);
         } else {
             const int grp = wave * 4 + q;
@@ -914,6 +920,50 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_fwd(const GemmParams& P, f3
     }
 }
 
+// EPI_ROPE_QKV: rope_kernel's arithmetic (elementwise.hip) on the bf16-ROUNDED projection, in the epilogue of the packed q|k|v GEMM.
+// The wave holds x1 = dims [32 (wc & 1), +32) of head (wc >> 1) in acc[i][0..1] and x2 = the same dims + 64 in acc[i][2..3] (B rows re-mapped
+// in pipe_tile); y1 = x1 cos - x2 sin, y2 = x2 cos + x1 sin with the fp32 table rows of the token's position.  Identical results to GEMM +
+// dllm_rope; the separate launch and its read + write of the q and k heads are gone.
+template <int MI>
+__device__ __forceinline__ void gemm_epilogue_rope(const GemmParams& P, f32x4 (&acc)[MI][4], char* wl, int64_t mw, int64_t n0, int wn, int lane) {
+    bf16* C = reinterpret_cast<bf16*>(P.C);
+    const int wc = wn >> 6;
+    const int64_t c0 = n0 + (wc >> 1) * 128 + (wc & 1) * 32;   // output column of the wave's first x1 dim
+    const int d0 = (wc & 1) * 32 + (lane >> 4) * 4;             // the lane's first dim (of the 64 pair dims) for j = 0
+#pragma unroll
+    for (int half = 0; half < MI / 4; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int i = half * 4 + ii;
+            const int r = ii * 16 + (lane & 15);
+            const int sw = ((r >> 1) & 7) << 1;
+            const int64_t m = mw + i * 16 + (lane & 15);
+            const int64_t p = P.rope_pos ? P.rope_pos[m] : (m % P.rope_S);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x4 cc = *reinterpret_cast<const f32x4*>(P.rope_cos + p * 64 + d0 + j * 16);
+                const f32x4 ss = *reinterpret_cast<const f32x4*>(P.rope_sin + p * 64 + d0 + j * 16);
+                bf16x4 o1, o2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float y1, y2;
+                    rope_pair((float)(bf16)(acc[i][j][e] * P.alpha), (float)(bf16)(acc[i][j + 2][e] * P.alpha), cc[e], ss[e], y1, y2);
+                    o1[e] = (bf16)y1;
+                    o2[e] = (bf16)y2;
+                }
+                *reinterpret_cast<bf16x4*>(wl + r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3)) = o1;
+                *reinterpret_cast<bf16x4*>(wl + r * 128 + ((((j + 2) * 4 + (lane >> 4)) ^ sw) << 3)) = o2;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + (lane >> 3), p = lane & 7;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(wl + row * 128 + ((p ^ ((row >> 1) & 7)) << 4));
+            st_bf16x8(C + (mw + half * 64 + row) * P.ldc + c0 + ((p & 4) ? 64 : 0) + (p & 3) * 8, v);
+        }
+    }
+}
+
 template <int MI>
 __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmParams& P, f32x4 (&acc)[MI][4], char* wl, int64_t mw, int64_t nw, int lane) {
     bf16* dgu = reinterpret_cast<bf16*>(P.C);
@@ -1005,6 +1055,14 @@ __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
 
     pipe_tile<AL, BL, BN_>(P, smem, m0, n0, 0, (int)(P.K / BK), acc);
 
+    if constexpr (AL == A_K && BL == B_K && BN_ == 256) {   // fused RoPE epilogue of the q and k column tiles (the v tiles take the plain path below)
+        if (P.epi == EPI_ROPE_QKV && n0 < P.rope_cols) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            gemm_epilogue_rope<MI>(P, acc, smem + wave * 8192, m0 + wm, n0, wn, lane);
+            return;
+        }
+    }
     if constexpr (AL == A_K && BN_ == 256) {   // fused SwiGLU epilogues (full tiles by construction of their entry points)
         if (P.epi == (BL == B_K ? EPI_SWIGLU_FWD : EPI_SWIGLU_BWD)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1491,6 +1549,28 @@ int dllm_gemm_swiglu_fwd(const void* x, const void* wgu, void* gu, void* act, in
     P.M = M; P.N = 2 * F; P.K = K; P.lda = ldx; P.ldb = ldw; P.ldc = ldgu; P.ld_aux_out = ldact; P.glu_F = F;
     P.epi = EPI_SWIGLU_FWD; P.alpha = 1.f; P.splitk = 1; P.group_m = group_m > 0 ? group_m : 4;
     const int64_t tiles = (M / 256) * (2 * F / 256);
+    if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+    constexpr int LDS = 2 * 2 * 256 * BK * 2;
+    static std::atomic<uint64_t> lds_ok{0};
+    dllm_ensure_dyn_lds(&gemm_pipe_kernel<A_K, B_K>, LDS, lds_ok);
+    hipLaunchKernelGGL((gemm_pipe_kernel<A_K, B_K>), dim3((unsigned)tiles), dim3(512), LDS, (hipStream_t)stream, P);
+    return dllm_check_launch();
+}
+// DreamLLMAttention's q / k / v projections as ONE GEMM on the packed [(Hq + 2 Hkv) * 128, K] weight with apply_rotary_pos_emb
+// (modeling_dreamllm.py:184-209,336-338) on the q and k heads in its epilogue (SURVEY §8(b2) `rope` epilogue).  rope_cols = (Hq + Hkv) * 128;
+// cos / sin: fp32 [max_pos][64]; pos: int64 [M] or NULL (position = row % S).  head_dim 128 only; M % 256 == 0, N % 256 == 0, rope_cols % 256 == 0,
+// K % 64 == 0.  Same results as dllm_gemm_bf16 + dllm_rope, bit for bit.
+int dllm_gemm_rope_qkv(const void* x, const void* wqkv, void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* pos, int64_t M,
+                       int64_t N, int64_t K, int64_t rope_cols, int S, int64_t ldx, int64_t ldw, int64_t ldo, int group_m, void* stream) {
+    if (M <= 0 || N <= 0 || K < BK || (M % 256) || (N % 256) || (K % BK) || rope_cols <= 0 || rope_cols > N || (rope_cols % 256) || S <= 0) return DLLM_ERR_SHAPE;
+    if (cos_tab == nullptr || sin_tab == nullptr) return DLLM_ERR_SHAPE;
+    if (!aligned16(x) || !aligned16(wqkv) || !aligned16(qkv) || !aligned16(cos_tab) || !aligned16(sin_tab) || ((ldx | ldw | ldo) & 7)) return DLLM_ERR_ALIGN;
+    GemmParams P{};
+    P.A = (const bf16*)x; P.B = (const bf16*)wqkv; P.C = qkv;
+    P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldb = ldw; P.ldc = ldo;
+    P.rope_cos = cos_tab; P.rope_sin = sin_tab; P.rope_pos = pos; P.rope_S = S; P.rope_cols = rope_cols;
+    P.epi = EPI_ROPE_QKV; P.alpha = 1.f; P.splitk = 1; P.group_m = group_m > 0 ? group_m : 4;
+    const int64_t tiles = (M / 256) * (N / 256);
     if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
     constexpr int LDS = 2 * 2 * 256 * BK * 2;
     static std::atomic<uint64_t> lds_ok{0};

@@ -43,6 +43,12 @@ struct GemmParams {
     const bf16* aux_in;   // BWD: the forward's packed [M, 2F] gate|up buffer
     bf16* aux_out;        // FWD: act [M, F] = silu(gate) * up
     int64_t ld_aux_in, ld_aux_out, glu_F;
+    // fused RoPE epilogue of the packed q|k|v projection (gemm.hip: EPI_ROPE_QKV): fp32 [max_pos][64] half-dim tables, positions or null
+    const float* rope_cos;
+    const float* rope_sin;
+    const int64_t* rope_pos;   // [M] position ids, or null: position = row % rope_S
+    int rope_S;
+    int64_t rope_cols;         // leading output columns that are rotated (q heads + k heads; head_dim 128), the rest (v) is plain
 };
 
 namespace {
@@ -56,7 +62,8 @@ constexpr int EPI_NONE = 0, EPI_GELU = 1, EPI_QUICK_GELU = 2, EPI_SILU = 3;
 constexpr int EPI_GEGLU = 4;  // gemm_ring.hip only: out[M, F] = (x Wh^T + bh) * gelu(x Wg^T + bg), weight rows [hidden F | gate F]
 // gemm.hip, pipelined 256 x 256 kernel only (DreamLLMMLP, modeling_dreamllm.py:237: down(silu(gate(x)) * up(x))):
 constexpr int EPI_SWIGLU_FWD = 5;  // C = [M, 2F] gate|up (as the plain GEMM) AND aux_out = silu(gate) * up, one launch
-constexpr int EPI_SWIGLU_BWD = 6;  // the down projection's input gradient d_act = dy Wd never leaves the block: C = [M, 2F] d(gate|up)
+constexpr int EPI_SWIGLU_BWD = 6;
+constexpr int EPI_ROPE_QKV = 7;    // packed q|k|v projection with apply_rotary_pos_emb (modeling_dreamllm.py:184-209) on the q and k heads in the epilogue  // the down projection's input gradient d_act = dy Wd never leaves the block: C = [M, 2F] d(gate|up)
 
 // ---- LDS images -------------------------------------------------------------------------------------------------
 // k-contiguous tile: [128 rows][64 k] bf16, 128 B per row, 16-B chunk c stored at chunk c ^ ((row >> 1) & 7):

@@ -185,7 +185,11 @@ class _DecoderLayerFn(torch.autograd.Function):
         nq, nkv = n_heads * hd, n_kv * hd
         h, _, rstd1 = ops.rmsnorm_fwd(x, w_in, eps)
         wqkv = _packed_view(wq, wk, wv)
-        if wqkv is not None:
+        roped = False
+        fused = ops.linear_rope_qkv(h.view(T, Hd), wqkv, cos, sin, pos, n_heads + n_kv, hd, S) if wqkv is not None else None
+        if fused is not None:          # q|k|v projection with the rotary embedding in its epilogue (round 6)
+            qkv, roped = fused.view(B, S, nq + 2 * nkv), True
+        elif wqkv is not None:
             qkv = ops.linear_fwd(h, wqkv).view(B, S, nq + 2 * nkv)
         else:
             qkv = torch.empty(B, S, nq + 2 * nkv, dtype=x.dtype, device=x.device)
@@ -195,8 +199,9 @@ class _DecoderLayerFn(torch.autograd.Function):
             ops.gemm(h2d, wv, T, nkv, Hd, Hd, Hd, 0, 0, out=o2d[:, nq + nkv:])
         h_keep = h if (keep and (ng[2] or ng[3] or ng[4])) else None   # kept tensors only feed weight gradients (a frozen LLM keeps nothing extra)
         del h
-        qk = qkv[:, :, : nq + nkv].unflatten(-1, (n_heads + n_kv, hd))   # q heads then k heads: one RoPE launch
-        ops.rope_(qk, cos, sin, pos)
+        if not roped:
+            qk = qkv[:, :, : nq + nkv].unflatten(-1, (n_heads + n_kv, hd))   # q heads then k heads: one RoPE launch
+            ops.rope_(qk, cos, sin, pos)
         q = qkv[:, :, :nq].unflatten(-1, (n_heads, hd))
         k = qkv[:, :, nq:nq + nkv].unflatten(-1, (n_kv, hd))
         v = qkv[:, :, nq + nkv:].unflatten(-1, (n_kv, hd))

@@ -430,6 +430,38 @@ def linear_swiglu_fwd(x, wgu):
     return gu, act
 
 
+FUSED_ROPE = os.environ.get("DREAMLLM_FUSED_ROPE", "1") != "0"
+
+
+def linear_rope_qkv(x, wqkv, cos, sin, pos, n_rot_heads, head_dim, S):
+    """qkv = x wqkv^T with the rotary embedding applied to the first `n_rot_heads` heads (the q and k heads of the packed q|k|v
+    projection) in the GEMM's epilogue (csrc/gemm.hip gemm_epilogue_rope): the same results as `linear_fwd` + `rope_`, one launch.
+    x [M, K]; wqkv [N, K]; cos / sin fp32 [P, 64]; pos int64 [M] or None (position = row % S).  None for shapes it does not take."""
+    if not FUSED_ROPE or (GEMM_VARIANT & 0xffff) not in (0, 259) or head_dim != 128:
+        return None
+    x2 = _as2d(x)
+    M, K = x2.shape
+    N = wqkv.shape[0]
+    rope_cols = n_rot_heads * head_dim
+    if M % 256 or N % 256 or rope_cols % 256 or rope_cols > N or K % 64 or K < 64 or not wqkv.is_contiguous():
+        return None
+    if cos.dtype != torch.float32 or sin.dtype != torch.float32 or cos.shape[-1] != 64 or not cos.is_contiguous() or not sin.is_contiguous():
+        return None
+    _need_gpu(x2, wqkv, cos, sin, pos)
+    _bf16(x2, wqkv)
+    if pos is not None:
+        pos = pos.reshape(-1)
+        if pos.numel() != M:
+            return None
+        if pos.dtype != torch.int64:
+            pos = pos.long()
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    with _GemmTimer(2.0 * M * N * K, "fwd_rope"):
+        check("dllm_gemm_rope_qkv", _p(x2), _p(wqkv), _p(out), _p(cos), _p(sin), _p(pos), M, N, K, rope_cols, int(S), x2.stride(0), K, N,
+              _glu_group_m((0, 0), M, N, K), _stream())
+    return out
+
+
 def linear_dgrad_swiglu(dy, wd, gu, dgu=None):
     """d(gate|up) [M, 2F] of act = silu(gate) * up, given dy [M, D] of the down projection (weight wd [D, F]) and the forward's packed
     gate|up buffer: the input gradient d_act = dy wd never leaves the GEMM.  None for shapes the fused kernel does not take."""

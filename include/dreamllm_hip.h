@@ -130,6 +130,13 @@ int dllm_gemm_swiglu_fwd(const void* x, const void* wgu, void* gu, void* act, in
                          int64_t ldgu, int64_t ldact, int group_m, void* stream);
 int dllm_gemm_swiglu_bwd(const void* dy, const void* wd, const void* gu, void* dgu, int64_t M, int64_t F, int64_t D, int64_t lddy,
                          int64_t ldw, int64_t ldgu, int64_t lddgu, int group_m, void* stream);
+/* DreamLLMAttention.forward, modeling_dreamllm.py:336-338 + apply_rotary_pos_emb :184-209 (SURVEY §8(b2) `rope` epilogue; round 6): the packed
+ * q|k|v projection qkv[M, N] = x wqkv^T with the rotary embedding applied to its first rope_cols = (Hq + Hkv) * 128 columns (head_dim 128) in the
+ * GEMM's epilogue.  cos_tab / sin_tab: fp32 [max_pos][64]; pos: int64 [M] position ids or NULL (position = row % S).  Same arithmetic on the
+ * same bf16-rounded projection as dllm_gemm_bf16 + dllm_rope: identical results.  M % 256 == 0, N % 256 == 0, rope_cols % 256 == 0, K % 64 == 0,
+ * 16-byte aligned pointers, leading dimensions % 8 == 0; otherwise DLLM_ERR_SHAPE / _ALIGN (the caller runs the two launches). */
+int dllm_gemm_rope_qkv(const void* x, const void* wqkv, void* qkv, const float* cos_tab, const float* sin_tab, const int64_t* pos, int64_t M,
+                       int64_t N, int64_t K, int64_t rope_cols, int S, int64_t ldx, int64_t ldw, int64_t ldo, int group_m, void* stream);
 int dllm_conv2d_nhwc_bf16_splitk(const void* x, const void* w, void* out, const void* bias, const void* residual,
                                  const void* image_bias, int NB, int H, int W, int C, int OH, int OW, int CO, int KH, int KW,
                                  int stride, int pad, int up2, int even_only, int epi, int out_dtype, int splitk,

@@ -1166,3 +1166,36 @@ def test_gemm_w4_experiment(M, N, K):
     with ops.gemm_variant(259):
         y0 = ops.linear_fwd(x.to(DEV), w.to(DEV))
     assert rel_l2(y, y0.float()) < 3e-3
+
+
+@pytest.mark.parametrize("M,Hq,Hkv,K,with_pos", [(256, 2, 2, 64, False), (512, 4, 2, 256, True), (1024, 6, 2, 320, False), (2048, 32, 32, 4096, True)])
+def test_gemm_rope_qkv_equals_gemm_plus_rope(M, Hq, Hkv, K, with_pos):
+    """packed q|k|v projection with the rotary embedding in its epilogue (dllm_gemm_rope_qkv, head_dim 128) == GEMM + dllm_rope on the q and
+    k heads, bit for bit (where the plain GEMM runs on the same kernel), v columns untouched; against the fp32 oracle by tolerance."""
+    ops = _ops()
+    from oracle import llm_ref
+    D, S = 128, 256
+    torch.manual_seed(M + Hq + K)
+    N = (Hq + 2 * Hkv) * D
+    x, w = rnd(M, K).to(DEV), rnd(N, K, scale=K ** -0.5).to(DEV)
+    cos, sin = llm_ref.rope_tables(D, 512)
+    ct, st = cos[:, : D // 2].contiguous().to(DEV), sin[:, : D // 2].contiguous().to(DEV)
+    pos = torch.randint(0, 512, (M,), device=DEV) if with_pos else None
+    y = ops.linear_rope_qkv(x, w, ct, st, pos, Hq + Hkv, D, S)
+    assert y is not None
+    with ops.gemm_variant(259):
+        y0 = ops.linear_fwd(x, w)
+    B = M // S
+    ops.rope_(y0.view(B, S, Hq + 2 * Hkv, D)[:, :, : Hq + Hkv], ct, st, pos)
+    if (M // 256) * (N // 256) >= 128 or K <= 320:
+        assert torch.equal(y, y0)
+    else:
+        assert rel_l2(y, y0.float()) < 2e-3
+    # fp32 oracle: rotate the fp32 projection
+    ref = (x.float().cpu() @ w.float().cpu().t()).view(M, Hq + 2 * Hkv, D)
+    p = (pos.cpu() if with_pos else torch.arange(M) % S)
+    c, s_ = cos[p][:, None, :], sin[p][:, None, :]
+    rot = torch.cat([-ref[..., D // 2:], ref[..., : D // 2]], -1)
+    ref_r = ref.clone()
+    ref_r[:, : Hq + Hkv] = (ref * c + rot * s_)[:, : Hq + Hkv]
+    assert rel_l2(y.view(M, -1, D), ref_r) < 6e-3
