@@ -403,7 +403,9 @@ def main():
 
     # ------------------------------------------------------------------ secondary leg: ragged documents (SURVEY §8d "Synthetic inputs")
     # S ~ U{S/2 .. S} per document, right-padded to S, `seqlens` passed: the varlen path of modeling_dreamllm.py:521-545 (per-row spans in
-    # the attention kernels, loss on the labelled rows).  Same model / optimizer state; 1 warm-up + `--ragged-steps` timed steps.
+    # the attention kernels, loss on the labelled rows).  Round 6: the decoder runs on COMPACT rows (valid tokens back to back; attention
+    # alone on the padded grid -- modeling_dreamllm._token_pack; DREAMLLM_PACK_RAGGED=0 restores the padded-grid GEMMs of the reference).
+    # Same model / optimizer state; 1 warm-up + `--ragged-steps` timed steps.
     ragged = None
     if not a.no_train and not a.no_ragged and not tiny and world == 1:   # N = 1 only: a rank that fails alone inside this try
         try:                                                                  # would leave the others in a collective
@@ -443,8 +445,8 @@ def main():
                                         achieved=round(gs / tsr / 1e12, 1) if tsr > 0 else None, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                                         frac=round(gs / tsr / 1e12 / PEAK_BF16_TFLOPS, 4) if tsr > 0 else None, traffic=None,
                                         launches_per_step=len(profr) // max(a.ragged_steps, 1), time_share_of_step=round(tsr / dtr, 4),
-                                        note="GEMMs run on the padded [B, S] token grid (executed FLOPs of the launches, as in the dense "
-                                             "leg); e2e_frac_mfma_peak beside it uses the algorithmic FLOPs of the actual lengths"))
+                                        note="the decoder's GEMMs run on the compact rows of the valid tokens (round 6; executed FLOPs of the "
+                                             "launches); e2e_frac_mfma_peak beside it uses the algorithmic FLOPs of the actual lengths"))
         except Exception as ex:  # secondary leg: never lose the headline line
             ragged = {"error": repr(ex)}
 

@@ -175,7 +175,7 @@ class _DecoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def _run_forward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, n_heads, n_kv, eps, need_bwd, ng,
-                     keep, want_y=True):
+                     keep, want_y=True, pack=None):
         """The layer's forward launches.  Returns (y, (k, v) views of the packed q|k|v buffer, the intermediates the backward reads).
         `want_y=False` (the recompute pass of `gradient_checkpointing`) stops in front of the down projection: nothing behind it is
         needed by the backward."""
@@ -202,11 +202,20 @@ class _DecoderLayerFn(torch.autograd.Function):
         if not roped:
             qk = qkv[:, :, : nq + nkv].unflatten(-1, (n_heads + n_kv, hd))   # q heads then k heads: one RoPE launch
             ops.rope_(qk, cos, sin, pos)
+        if pack is not None:
+            # ragged batch on COMPACT rows (`_token_pack`): every GEMM / norm of the layer runs on the valid tokens only; attention alone
+            # needs the padded [PB, PS] grid (one span per row), so q|k|v are scattered onto it and the output gathered back -- the
+            # reference's unpad / pad round trip (modeling_dreamllm.py:523-545) the other way round
+            vidx, tv, PB, PS = pack
+            qkv_p = torch.empty(PB, PS, nq + 2 * nkv, dtype=x.dtype, device=x.device)
+            ops.scatter_rows_(qkv_p.view(PB * PS, -1), vidx[:tv], qkv.view(T, -1)[:tv])
+            qkv = qkv_p      # what the backward keeps
         q = qkv[:, :, :nq].unflatten(-1, (n_heads, hd))
         k = qkv[:, :, nq:nq + nkv].unflatten(-1, (n_kv, hd))
         v = qkv[:, :, nq + nkv:].unflatten(-1, (n_kv, hd))
         o, lse = ops.attn_fwd(q, k, v, True, 1.0 / math.sqrt(hd), seqlens, need_lse=need_bwd, seqstart=seqstart)
-        x2 = ops.linear_fwd(o.view(B, S, Hd), wo, residual=x)
+        o_c = o if pack is None else ops.gather_rows(o.view(-1, Hd), pack[0])   # (filler rows read a pad position: zeros)
+        x2 = ops.linear_fwd(o_c.view(B, S, Hd), wo, residual=x)
         h2, _, rstd2 = ops.rmsnorm_fwd(x2, w_post, eps)
         F_ = wg.shape[0]
         wgu = _packed_view(wg, wu)
@@ -231,7 +240,7 @@ class _DecoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, n_heads, n_kv, eps, want_kv,
-                recompute=False):
+                recompute=False, pack=None):
         need_bwd = any(ctx.needs_input_grad[:10])
         ng = ctx.needs_input_grad
         # `recompute` = whole-layer activation recompute (the reference's gradient checkpointing, modeling_dreamllm.py:994-1003,
@@ -239,8 +248,11 @@ class _DecoderLayerFn(torch.autograd.Function):
         # and then proceeds as usual -- same kernels on the same inputs, so the gradients are bit-identical to the keeping path.
         recompute = bool(recompute) and need_bwd
         keep = need_bwd and KEEP_LAYER_ACTIVATIONS and not recompute
+        if pack is not None and want_kv:
+            raise ValueError("packed ragged rows are a training path: no KV cache")
         y, (k, v), inter = _DecoderLayerFn._run_forward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart,
-                                                        n_heads, n_kv, eps, need_bwd, ng, keep)
+                                                        n_heads, n_kv, eps, need_bwd, ng, keep, pack=pack)
+        ctx.pack = pack
         if need_bwd:
             if recompute:
                 ctx.save_for_backward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart)
@@ -262,7 +274,7 @@ class _DecoderLayerFn(torch.autograd.Function):
             with torch.no_grad():   # intermediates of this layer only: freed again when this backward returns
                 _, _, inter = _DecoderLayerFn._run_forward(x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart,
                                                            n_heads, n_kv, eps, True, ctx.needs_input_grad, KEEP_LAYER_ACTIVATIONS,
-                                                           want_y=False)
+                                                           want_y=False, pack=ctx.pack)
             rstd1, qkv, o, lse, x2, rstd2, gu, h_keep, h2_keep, act_keep = inter
         else:
             (x, w_in, wq, wk, wv, wo, w_post, wg, wu, wd, cos, sin, pos, seqlens, seqstart, rstd1, qkv, o, lse, x2, rstd2,
@@ -314,8 +326,17 @@ class _DecoderLayerFn(torch.autograd.Function):
         dx2, dw_post = ops.rmsnorm_bwd(dh2, x2, w_post, rstd2, dh_in=dy, need_dw=need[6])
         del dh2
         # ---- attention
-        do = ops.linear_dgrad(dx2, wo).view(B, S, n_heads, hd)
-        dwo = ops.linear_wgrad(dx2, o.view(B, S, Hd)) if need[5] else None
+        pack = ctx.pack
+        do = ops.linear_dgrad(dx2, wo)
+        if pack is None:
+            do = do.view(B, S, n_heads, hd)
+            dwo = ops.linear_wgrad(dx2, o.view(B, S, Hd)) if need[5] else None
+        else:   # compact rows: qkv / o were kept on the padded [PB, PS] grid the attention kernels ran on (see _run_forward)
+            vidx, tv, PB, PS = pack
+            dwo = ops.linear_wgrad(dx2, ops.gather_rows(o.view(-1, Hd), vidx)) if need[5] else None
+            do_p = torch.zeros(PB * PS, Hd, dtype=x.dtype, device=x.device)
+            ops.scatter_rows_(do_p, vidx[:tv], do.view(T, Hd)[:tv])
+            do = do_p.view(PB, PS, n_heads, hd)
         q = qkv[:, :, :nq].unflatten(-1, (n_heads, hd))
         k = qkv[:, :, nq:nq + nkv].unflatten(-1, (n_kv, hd))
         v = qkv[:, :, nq + nkv:].unflatten(-1, (n_kv, hd))
@@ -324,6 +345,8 @@ class _DecoderLayerFn(torch.autograd.Function):
         ops.attn_bwd(do, q, k, v, o, lse, True, 1.0 / math.sqrt(hd), seqlens, dq=dqkv[:, :, :nq].unflatten(-1, (n_heads, hd)),
                      dk=dk_, dv=dv_, seqstart=seqstart)
         del do
+        if pack is not None:   # back to compact rows (filler rows read a pad position: the backward kernels write zeros there)
+            dqkv = ops.gather_rows(dqkv.view(-1, nq + 2 * nkv), pack[0]).view(B, S, nq + 2 * nkv)
         ops.rope_(dqkv[:, :, : nq + nkv].unflatten(-1, (n_heads + n_kv, hd)), cos, sin, pos, backward=True)
         d2 = dqkv.view(T, nq + 2 * nkv)
         wqkv = _packed_view(wq, wk, wv)
@@ -349,7 +372,7 @@ class _DecoderLayerFn(torch.autograd.Function):
             ops.gemm(d2[:, nq:nq + nkv], wk, T, Hd, nkv, ld, Hd, 0, 1, out=dh, accumulate=True)
             ops.gemm(d2[:, nq + nkv:], wv, T, Hd, nkv, ld, Hd, 0, 1, out=dh, accumulate=True)
         dx, dw_in = ops.rmsnorm_bwd(dh, x, w_in, rstd1, dh_in=dx2, need_dw=need[1])
-        return (dx.view(x.shape), dw_in, dwq, dwk, dwv, dwo, dw_post, dwg, dwu, dwd) + (None,) * 10
+        return (dx.view(x.shape), dw_in, dwq, dwk, dwv, dwo, dw_post, dwg, dwu, dwd) + (None,) * 11
 
 
 class DreamLLMMLP(nn.Module):
@@ -595,7 +618,7 @@ class DreamLLMDecoderLayer(nn.Module):
                 a.o_proj.weight, self.post_attention_layernorm.weight, self.mlp.gate_proj.weight, self.mlp.up_proj.weight,
                 self.mlp.down_proj.weight, cos, sin, pos, seqlens, seqstart, a.num_heads, a.num_key_value_heads,
                 self.input_layernorm.variance_epsilon, bool(use_cache),
-                bool(kwargs.get("recompute", False)) and self.training and torch.is_grad_enabled())
+                bool(kwargs.get("recompute", False)) and self.training and torch.is_grad_enabled(), kwargs.get("pack"))
             outputs = (y,)
             if use_cache:
                 outputs += ((k.transpose(1, 2), v.transpose(1, 2)),)
@@ -777,6 +800,31 @@ def _slot_indices(input_ids, start_id, length, max_slots=None):
     return idx.reshape(-1), starts.numel()
 
 
+# Ragged training batches (right-padded rows, `seqlens` known): the decoder runs on COMPACT rows -- the valid tokens of all rows back to
+# back, filled up to a multiple of 256 rows with copies of one pad position -- so that the GEMMs, norms and element-wise passes (83 % of the
+# step) do not compute on padding; only attention sees the padded grid (`_DecoderLayerFn._run_forward`).  The reference's flash path unpads
+# around attention alone (modeling_dreamllm.py:523-545) and computes everything else on the padded grid; results at valid positions are the
+# same, pad positions of the returned hidden states are zeros.  PACK_RAGGED_MIN_SAVING: below this share of padding it is not worth it.
+PACK_RAGGED = os.environ.get("DREAMLLM_PACK_RAGGED", "1") != "0"
+PACK_RAGGED_MIN_SAVING = 0.06
+
+
+def _token_pack(seqlens, B, S, device):
+    """(vidx int64 [Tvp] device, tv, B, S, pos int64 [Tvp] device) or None.  One device->host read of the B lengths per forward."""
+    lens = [max(0, min(int(v), S)) for v in seqlens.tolist()]
+    tv = sum(lens)
+    if tv == 0 or tv > (1.0 - PACK_RAGGED_MIN_SAVING) * B * S:
+        return None
+    tvp = (tv + 255) // 256 * 256
+    if tvp >= B * S:
+        return None
+    b_pad = next(b for b, L in enumerate(lens) if L < S)
+    idx = torch.cat([torch.arange(L, dtype=torch.int64) + b * S for b, L in enumerate(lens)] +
+                    [torch.full((tvp - tv,), b_pad * S + lens[b_pad], dtype=torch.int64)])
+    pos = torch.cat([torch.arange(L, dtype=torch.int64) for L in lens] + [torch.zeros(tvp - tv, dtype=torch.int64)])
+    return idx.to(device, non_blocking=True), tv, B, S, pos.to(device, non_blocking=True)
+
+
 class DreamLLMModel(DreamLLMPreTrainedModel):
     """modeling_dreamllm.py:803-1169."""
 
@@ -879,6 +927,18 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
             extra["recompute"] = True
         if torch.compiler.is_compiling() and not torch.is_grad_enabled() and past_key_values is None and len(self.layers) > 0:
             extra["rope_tables"] = self.layers[0].self_attn.rotary_emb.tables(seq_length, hidden_states.device)
+        pack = None
+        if (PACK_RAGGED and self.training and torch.is_grad_enabled() and hidden_states.is_cuda and past_key_values is None and not use_cache
+                and not output_hidden_states and seqlens is not None and seqstart is None and unperm_order is None and batch_size > 1
+                and getattr(self.config, "pack_ragged_tokens", True) and not torch.compiler.is_compiling()):
+            pack = _token_pack(seqlens, batch_size, seq_length, hidden_states.device)
+        if pack is not None:
+            vidx, tv, _, _, ppos = pack
+            if position_ids is not None:   # explicit positions travel with their tokens
+                ppos = position_ids.expand(batch_size, seq_length).reshape(-1)[vidx].long()
+            hidden_states = ops.PackRowsFn.apply(hidden_states.reshape(batch_size * seq_length, -1), vidx, tv)[None]
+            position_ids = ppos[None]
+            extra["pack"] = (vidx, tv, batch_size, seq_length)
         for idx, decoder_layer in enumerate(self.layers):
             if output_hidden_states:
                 all_hidden_states += (hidden_states,)
@@ -890,6 +950,8 @@ class DreamLLMModel(DreamLLMPreTrainedModel):
             if use_cache:
                 next_decoder_cache += (layer_outputs[1],)
         hidden_states = self.norm(hidden_states)
+        if pack is not None:   # back to the padded grid the caller indexes (zeros at pad positions)
+            hidden_states = ops.UnpackRowsFn.apply(hidden_states[0], pack[0], pack[1], batch_size * seq_length).view(batch_size, seq_length, -1)
         if output_hidden_states:
             all_hidden_states += (hidden_states,)
         if unperm_order is not None:  # back to the caller's token order

@@ -296,7 +296,7 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     cnt = _splitk_counters(a.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-M // 128) * -(-N // 128) <= 16384) else None
     variant = GEMM_VARIANT | (persist & STREAMK_WS_BIT)
     if (variant & 0xffff) == 0 and sk == 1 and (variant >> 16) & 0xff == 0:
-        gm = _GROUP_M_TABLE.get((layout_a, layout_b, M, N, K), 0)
+        gm = _group_m_for(layout_a, layout_b, M, N, K)
         if gm == 0 and GEMM_TUNE_GROUP_M and 2.0 * M * N * K >= _TUNE_MIN_FLOPS:   # opt-in tool, off in the product path
             gm = _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha)
         variant = (gm << 16) | persist
@@ -336,6 +336,20 @@ def _load_group_m_table():
 
 
 _GROUP_M_TABLE = _load_group_m_table()  # (layout_a, layout_b, M, N, K) -> GROUP_M
+# The table was measured at T = 32768 tokens; ragged batches on compact rows (round 6) run the same weights at other token counts.  The token
+# count is M of the forward / dgrad layouts and K of the weight-gradient layout: a second key without it serves those calls (>= 8192 tokens).
+_GROUP_M_BY_WEIGHT = {}
+for (_la, _lb, _M, _N, _K), _gm in _GROUP_M_TABLE.items():
+    _GROUP_M_BY_WEIGHT[(_la, _lb, _M, _N) if (_la, _lb) == (1, 1) else (_la, _lb, _N, _K)] = _gm
+
+
+def _group_m_for(layout_a, layout_b, M, N, K):
+    gm = _GROUP_M_TABLE.get((layout_a, layout_b, M, N, K), 0)
+    if gm == 0:
+        tokens = K if (layout_a, layout_b) == (1, 1) else M
+        if tokens >= 8192:
+            gm = _GROUP_M_BY_WEIGHT.get((layout_a, layout_b, M, N) if (layout_a, layout_b) == (1, 1) else (layout_a, layout_b, N, K), 0)
+    return gm
 
 
 def _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha):
@@ -406,7 +420,7 @@ FUSED_SWIGLU = os.environ.get("DREAMLLM_FUSED_SWIGLU", "1") != "0"
 
 
 def _glu_group_m(layout, M, N, K):
-    return _GROUP_M_TABLE.get((layout[0], layout[1], M, N, K), 0)
+    return _group_m_for(layout[0], layout[1], M, N, K)
 
 
 def linear_swiglu_fwd(x, wgu):
@@ -1062,6 +1076,44 @@ class GatherRowsFn(torch.autograd.Function):
 
 def gather_rows_unique(x2d, idx):
     return GatherRowsFn.apply(x2d, idx)
+
+
+class PackRowsFn(torch.autograd.Function):
+    """Padded token grid -> compact rows (ragged batches, round 6): out[i] = x[idx[i]] for the tv valid tokens; rows tv.. of the compact
+    matrix are filler (they repeat one pad position so that the row count is a multiple of the GEMM tile) and carry no gradient."""
+
+    @staticmethod
+    def forward(ctx, x2d, idx, tv):
+        ctx.save_for_backward(idx)
+        ctx.shape, ctx.tv = x2d.shape, tv
+        return gather_rows(x2d, idx)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        dx = torch.zeros(ctx.shape, dtype=dout.dtype, device=dout.device)
+        scatter_rows_(dx, idx[: ctx.tv], dout[: ctx.tv].contiguous())
+        return dx, None, None
+
+
+class UnpackRowsFn(torch.autograd.Function):
+    """Compact rows -> padded token grid [n_rows, H]: out[idx[i]] = rows[i] for the tv valid tokens, zeros elsewhere (pad_input
+    semantics, modeling_dreamllm.py:545)."""
+
+    @staticmethod
+    def forward(ctx, rows, idx, tv, n_rows):
+        ctx.save_for_backward(idx)
+        ctx.tv, ctx.rows_shape = tv, rows.shape
+        out = torch.zeros(n_rows, rows.shape[-1], dtype=rows.dtype, device=rows.device)
+        scatter_rows_(out, idx[:tv], rows[:tv].contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        d = torch.zeros(ctx.rows_shape, dtype=dout.dtype, device=dout.device)
+        d[: ctx.tv] = gather_rows(dout.contiguous(), idx[: ctx.tv])
+        return d, None, None, None
 
 
 LM_HEAD_CE_CHUNK_ROWS = int(os.environ.get("DREAMLLM_CE_CHUNK_ROWS", "4096"))  # rows of hidden states per chunk of the fused lm_head + CE (525 MB of fp32 logits at V = 32008)

@@ -547,3 +547,47 @@ def test_training_step_is_bit_reproducible():
         assert torch.equal(loss, loss0), rep
         for n in g0:
             assert torch.equal(g[n], g0[n]), (rep, n)
+
+
+def test_ragged_batch_on_compact_rows_matches_the_padded_grid():
+    """Round 6: a right-padded ragged training batch with `seqlens` runs the decoder on COMPACT rows (valid tokens back to back, attention
+    alone on the padded grid).  Loss, both loss terms and every gradient must agree with the padded-grid path (same kernels on the same
+    rows; only split-K choices and the weight gradients' token order may differ: bf16-level tolerance), hidden states at pad positions
+    are zeros, and a dense batch is untouched."""
+    from dreamllm_amd import modeling_dreamllm as MD
+    from dreamllm_amd.factory import TINY, TINY_CLIP, TINY_DIFFUSION, build_dreamllm
+    from dreamllm_amd.synthetic import make_interleaved_batch
+    m = build_dreamllm(dict(TINY, num_hidden_layers=3), device=DEV, seed=0, clip=TINY_CLIP, diffusion=TINY_DIFFUSION, num_dream_queries=8).train()
+    batch = make_interleaved_batch(6, 512, 1, n_dream=8, n_patch=16, seed=3, device=DEV, image_size=56, dm_size=128, ragged=True)
+    lens = batch["seqlens"].tolist()
+    assert sum(lens) < 0.9 * 6 * 512
+
+    def run(pack):
+        MD.PACK_RAGGED = pack
+        try:
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            out = m(**batch, return_dict=True)
+            out.loss.backward()
+            return out.loss.detach().float().item(), {n: p.grad.float().clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            MD.PACK_RAGGED = True
+
+    l0, g0 = run(False)
+    l1, g1 = run(True)
+    assert abs(l0 - l1) <= 2e-3 * abs(l0), (l0, l1)
+    assert g0.keys() == g1.keys()
+    worst = max(((g0[n] - g1[n]).norm() / (g0[n].norm() + 1e-12)).item() for n in g0)
+    assert worst < 2e-2, worst
+    # the model's hidden states: valid rows agree, pad rows are zeros
+    with torch.enable_grad():
+        MD.PACK_RAGGED = True
+        h1 = m.model(input_ids=batch["input_ids"], images=batch["images"], seqlens=batch["seqlens"], image_index=batch["image_index"],
+                     dream_index=batch["dream_index"], return_dict=True).last_hidden_state
+        MD.PACK_RAGGED = False
+        h0 = m.model(input_ids=batch["input_ids"], images=batch["images"], seqlens=batch["seqlens"], image_index=batch["image_index"],
+                     dream_index=batch["dream_index"], return_dict=True).last_hidden_state
+        MD.PACK_RAGGED = True
+    for b, L in enumerate(lens):
+        assert rel_l2(h1[b, :L], h0[b, :L].float()) < 1e-2
+        assert torch.count_nonzero(h1[b, L:]) == 0
