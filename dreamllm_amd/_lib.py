@@ -44,6 +44,7 @@ SIGNATURES = {
     "dllm_rope_append": [c_void_p] * 9 + [c_int] * 4 + [c_i64] * 5 + [c_void_p],
     "dllm_attn_decode": [c_void_p] * 7 + [c_int] * 4 + [c_i64] * 7 + [c_float, c_int, c_void_p],
     "dllm_attn_decode_rope": [c_void_p] * 13 + [c_int] * 4 + [c_i64] * 8 + [c_float, c_int, c_void_p],
+    "dllm_gemv_attn_combine": [c_void_p] * 4 + [c_int] * 4 + [c_i64] * 4 + [c_int, c_void_p],
     "dllm_attn_fwd": [c_void_p] * 7 + [c_int] * 6 + [c_i64] * 9 + [c_float, c_int, c_void_p],
     "dllm_attn_bwd": [c_void_p] * 12 + [c_int] * 6 + [c_i64] * 15 + [c_float, c_int, c_void_p],
     "dllm_rope": [c_void_p] * 4 + [c_i64, c_int, c_int, c_int, c_i64, c_i64, c_int, c_void_p],

@@ -93,6 +93,10 @@ struct GemvFusedParams {
     int K;
     int64_t ldx, ldw;
     int out_f32;
+    // round 6 (gemv_lds_kernel only): x = the merge of split-KV attention partials (ws of dllm_attn_decode[_rope], [M * H][NS][D + 2] floats),
+    // computed while the block stages x -- the combine launch between attention and the o projection disappears
+    const float* comb_ws;
+    int comb_ns, comb_H, comb_D;
 };
 
 template <int MB, bool SWIGLU>
@@ -289,6 +293,35 @@ __global__ __launch_bounds__(256) void gemv_lds_kernel(GemvFusedParams P, int it
         }
         __syncthreads();
     }
+    if (P.comb_ws != nullptr) {
+        // x[m][h * D + d] = attn_decode_combine_kernel's result for (batch m, head h), bit for bit: max over the splits, then l and o summed
+        // in split order with the same expressions, one rounding to bf16
+        const int D = P.comb_D, NS = P.comb_ns;
+        for (int k = threadIdx.x * 8; k < K; k += 2048) {
+            const int h = k / D, d0 = k - h * D;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const float* src = P.comb_ws + ((int64_t)(m * P.comb_H + h) * NS) * (D + 2);
+                float mx = -INFINITY;
+                for (int sp = 0; sp < NS; ++sp) mx = fmaxf(mx, src[sp * (D + 2) + D]);
+                float l = 0.f, o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = 0.f;
+                for (int sp = 0; sp < NS; ++sp) {
+                    const float ms = src[sp * (D + 2) + D];
+                    if (ms == -INFINITY) continue;
+                    const float c = exp2f(ms - mx);
+                    l += src[sp * (D + 2) + D + 1] * c;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += src[sp * (D + 2) + d0 + e] * c;
+                }
+                bf16x8 xv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xv[e] = (bf16)(l > 0.f ? o[e] / l : 0.f);
+                *reinterpret_cast<bf16x8*>(xs + (int64_t)m * K + k) = xv;
+            }
+        }
+    } else
     for (int k = threadIdx.x * 8; k < K; k += 2048) {
         bf16x8 nw = zero_bf16x8();
         if (P.norm_w != nullptr) nw = ld_bf16x8(P.norm_w + k);
@@ -660,7 +693,7 @@ static int launch_attn_decode(const void* q, void* kcache, void* vcache, const i
 #define DLLM_ATTN_DEC(DD, RR)                                                                                                     \
     hipLaunchKernelGGL((attn_decode_partial_kernel<DD, RR>), grid, dim3(256), 0, s, (const bf16*)q, (bf16*)kcache, (bf16*)vcache,  \
                        kv_len, kv_start, ws, H, Hkv, q_sb, q_sh, c_sb, c_ss, c_sh, scale, nsplit, rn)
-    const bool fused_combine = rope && rn.counters != nullptr;
+    const bool fused_combine = (rope && rn.counters != nullptr) || out == nullptr;   // out == NULL: the consumer merges the partials (dllm_gemv_attn_combine)
     if (D == 128) {
         if (rope) DLLM_ATTN_DEC(128, true); else DLLM_ATTN_DEC(128, false);
         if (!fused_combine)
@@ -772,6 +805,31 @@ int dllm_rope_append(void* q, const void* k, const void* v, void* kcache, void* 
 
 // floats of workspace dllm_attn_decode needs
 int64_t dllm_attn_decode_ws_floats(int B, int H, int D, int nsplit) { return (int64_t)B * H * nsplit * (D + 2); }
+
+// The o projection of a decode step fed DIRECTLY with the split-KV attention partials (round 6): y[M, N] = combine(ws) W^T (+ residual),
+// where combine is attn_decode_combine_kernel's merge (same bits), computed while every block stages its x -- call dllm_attn_decode[_rope]
+// with out = NULL (partials only) in front of it.  ws: fp32 [M * H][nsplit][D + 2]; W [N][ldw] with K = H * D columns; M <= 4.
+// Replaces the combine launch + dllm_gemv_bf16 of the o projection (modeling_dreamllm.py:395 in the token loop of
+// omni/eval/language_eval/modeling_dreamllm.py:76-97).
+int dllm_gemv_attn_combine(const float* ws, const void* W, void* y, const void* residual, int M, int H, int D, int nsplit, int64_t N,
+                           int64_t ldw, int64_t ldy, int64_t ldr, int out_dtype, void* stream) {
+    const int64_t K = (int64_t)H * D;
+    if (M < 1 || M > 4 || H <= 0 || (D != 64 && D != 128) || nsplit < 1 || nsplit > 64 || N < 0 || !gemv_lds_ok(M, K)) return DLLM_ERR_SHAPE;
+    if (ws == nullptr || (ldw & 7) || (reinterpret_cast<uintptr_t>(W) & 15)) return DLLM_ERR_ALIGN;
+    if (out_dtype != DLLM_BF16 && out_dtype != DLLM_F32) return DLLM_ERR_DTYPE;
+    if (N == 0) return DLLM_OK;
+    GemvFusedParams P{};
+    P.W[0] = (const bf16*)W; P.y[0] = y; P.N[0] = N; P.ldy[0] = ldy; P.residual = (const bf16*)residual; P.ldr = ldr; P.K = (int)K;
+    P.ldw = ldw; P.out_f32 = out_dtype == DLLM_F32;
+    P.comb_ws = ws; P.comb_ns = nsplit; P.comb_H = H; P.comb_D = D;
+    hipStream_t s = (hipStream_t)stream;
+    switch (M) {
+        case 1: return launch_gemv_lds<1>(P, 0, s);
+        case 2: return launch_gemv_lds<2>(P, 0, s);
+        case 3: return launch_gemv_lds<3>(P, 0, s);
+        default: return launch_gemv_lds<4>(P, 0, s);
+    }
+}
 
 // One query token per (b, h) against a KV cache [B][S_max][Hkv][D] (element strides c_sb, c_ss, c_sh; d contiguous) whose valid
 // length per batch element is read from DEVICE memory (kv_len[b], positions 0 .. kv_len[b]-1 attended).  q / out: [B][H][D]

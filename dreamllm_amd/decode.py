@@ -25,7 +25,7 @@ from . import ops
 
 class GreedyDecodeSession:
     def __init__(self, model, batch_size: int, max_len: int, use_graph: bool = True, nsplit: int = 8, fused: bool = True,
-                 vocab_limit: int | None = 32000, fuse_rope: bool = True, fuse_combine: bool = False):
+                 vocab_limit: int | None = 32000, fuse_rope: bool = True, fuse_combine: bool = False, merge_in_oproj: bool = False):
         """`vocab_limit`: argmax runs over `logits[..., :vocab_limit]` -- the reference loop slices `[..., :32000]`
         (omni/eval/language_eval/modeling_dreamllm.py:79,86) so that none of the added special tokens (<dream_start>, <im_*>,
         [PAD] ...) can be emitted; None = whole vocabulary."""
@@ -33,6 +33,11 @@ class GreedyDecodeSession:
         self.model = model
         self.B, self.max_len, self.use_graph, self.nsplit, self.fused = batch_size, max_len, use_graph, nsplit, fused
         self.fuse_rope = fuse_rope
+        # round 6 (opt-in, measured SLOWER: 298.6 against 308.3 tok/s in one process, profiles/r06_decode_merge_ab.log): the o projection's GEMV
+        # merges the split-KV partials itself while staging x (5 launches per layer instead of 6) -- each of its ~512 blocks then re-reads the
+        # 133 KB of partials from L2, which costs more than the 5.5 us combine launch it removes; LDS staging covers up to 4 sequences
+        self.merge_oproj = bool(merge_in_oproj) and fuse_rope and fused and batch_size <= 4 and \
+            batch_size * cfg.hidden_size * 2 <= 60 * 1024
         # arrival counters of the in-launch split-KV merge (zero at rest; one array per session = per stream in flight)
         self.attn_counters = (torch.zeros(batch_size * cfg.num_attention_heads, dtype=torch.int32, device=model.device)
                               if fuse_combine else None)
@@ -77,6 +82,16 @@ class GreedyDecodeSession:
                 q, k, v = ops.gemv_fused(x, (at.q_proj.weight, at.k_proj.weight, at.v_proj.weight),
                                          norm_w=layer.input_layernorm.weight, eps=eps)
                 q = q.view(B, H, D)
+                if self.merge_oproj:
+                    # round 6: 5 launches per layer -- the split-KV partials go straight into the o projection, whose blocks merge them
+                    # while staging x (no combine launch)
+                    ws = ops.attn_decode_rope(q, k.view(B, Hkv, D), v.view(B, Hkv, D), self.kc[li], self.vc[li], self.kv_len, self.cos,
+                                              self.sin, pos, 1.0 / math.sqrt(D), self.nsplit, kv_start=self.kv_start, partials_only=True)
+                    x2 = ops.gemv_attn_combine(ws, at.o_proj.weight, B, H, D, self.nsplit, residual=x)
+                    act = ops.gemv_fused(x2, (mlp.gate_proj.weight, mlp.up_proj.weight), norm_w=layer.post_attention_layernorm.weight,
+                                         eps=eps, swiglu=True)
+                    x = ops.gemv(act, mlp.down_proj.weight, residual=x2)
+                    continue
                 if self.fuse_rope:   # RoPE + cache append inside the attention launch (round 4)
                     o = ops.attn_decode_rope(q, k.view(B, Hkv, D), v.view(B, Hkv, D), self.kc[li], self.vc[li], self.kv_len, self.cos,
                                              self.sin, pos, 1.0 / math.sqrt(D), self.nsplit, kv_start=self.kv_start,

@@ -1595,11 +1595,12 @@ def attn_decode(q, kcache, vcache, kv_len, scale=None, nsplit=8, out=None, kv_st
 
 
 def attn_decode_rope(q, k_new, v_new, kcache, vcache, kv_len, cos, sin, pos, scale=None, nsplit=8, out=None, kv_start=None,
-                     counters=None):
+                     counters=None, partials_only=False):
     """`rope_append_` + `attn_decode` in one launch pair: q [B,H,D] UN-rotated (left untouched), k_new / v_new [B,Hkv,D] the step's
     key / value (k un-rotated); the kernel rotates q in registers, writes rotate(k_new) and v_new to cache slot kv_len[b] - 1 and
     attends to them in the same launch.  pos int64 [B] and kv_len int32 [B] on device.  `counters` (int32 [B*H], zero at rest): the
-    last split to finish merges the partial states inside the launch instead of a combine launch."""
+    last split to finish merges the partial states inside the launch instead of a combine launch.  `partials_only`: no merge at all --
+    returns the split-KV partial states (fp32 [B*H, nsplit, D+2]) for `gemv_attn_combine`, which merges them while it stages its x."""
     _need_gpu(q, k_new, v_new, kcache, vcache, kv_len, cos, sin, pos)
     _bf16(q, k_new, v_new, kcache, vcache)
     B, H, D = q.shape
@@ -1610,13 +1611,29 @@ def attn_decode_rope(q, k_new, v_new, kcache, vcache, kv_len, cos, sin, pos, sca
         raise ValueError("attn_decode_rope: contiguous k_new / v_new of shape [B, Hkv, D] required")
     if kv_len.dtype != torch.int32 or pos.dtype != torch.int64:
         raise TypeError("attn_decode_rope: kv_len must be int32, pos int64")
-    if out is None:
+    if out is None and not partials_only:
         out = torch.empty(B, H, D, dtype=q.dtype, device=q.device)
     ws = torch.empty(_lib.lib().dllm_attn_decode_ws_floats(B, H, D, nsplit), dtype=torch.float32, device=q.device)
     check("dllm_attn_decode_rope", _p(q), _p(k_new), _p(v_new), _p(kcache), _p(vcache), _p(cos), _p(sin), _p(pos.reshape(-1)), _p(kv_len),
-          _p(kv_start), _p(out), _p(ws), _p(counters), B, H, Hkv, D, q.stride(0), q.stride(1), k_new.stride(0), kcache.stride(0), kcache.stride(1),
-          kcache.stride(2), out.stride(0), out.stride(1), float(scale if scale is not None else D ** -0.5), nsplit, _stream())
-    return out
+          _p(kv_start), _p(None if partials_only else out), _p(ws), _p(None if partials_only else counters), B, H, Hkv, D, q.stride(0), q.stride(1),
+          k_new.stride(0), kcache.stride(0), kcache.stride(1), kcache.stride(2), H * D if partials_only else out.stride(0),
+          D if partials_only else out.stride(1), float(scale if scale is not None else D ** -0.5), nsplit, _stream())
+    return ws if partials_only else out
+
+
+def gemv_attn_combine(ws, w, B, H, D, nsplit, residual=None, out_dtype=torch.bfloat16):
+    """o projection of a token step straight from the split-KV partials of `attn_decode_rope(..., partials_only=True)`:
+    y [B, N] = merge(ws) w^T (+ residual), the merge being attn_decode's combine (same bits) done while each block stages x.
+    None when the shape is not covered (B > 4, H * D too large for the LDS staging): the caller combines and calls `gemv`."""
+    if B > 4 or B * H * D * 2 > 60 * 1024 or D not in (64, 128):
+        return None
+    _need_gpu(ws, w, residual)
+    _bf16(w, residual)
+    N = w.shape[0]
+    y = torch.empty(B, N, dtype=out_dtype, device=w.device)
+    check("dllm_gemv_attn_combine", _p(ws), _p(w), _p(y), _p(residual), B, H, D, nsplit, N, w.stride(0), y.stride(0),
+          residual.stride(0) if residual is not None else 0, _dt(y), _stream())
+    return y
 
 
 # --------------------------------------------------------------------------------------------- torch.compile coexistence

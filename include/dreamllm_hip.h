@@ -282,6 +282,11 @@ int dllm_attn_decode_rope(const void* q, const void* k_new, const void* v_new, v
                           const float* sin_tab, const int64_t* pos, const int* kv_len, const int* kv_start, void* out, float* ws,
                           int* counters, int B, int H, int Hkv, int D, int64_t q_sb, int64_t q_sh, int64_t kv_sb, int64_t c_sb,
                           int64_t c_ss, int64_t c_sh, int64_t o_sb, int64_t o_sh, float scale, int nsplit, void* stream);
+/* The o projection of a token step fed directly with the split-KV partials of dllm_attn_decode[_rope] called with out = NULL (round 6):
+ * y[M, N] = merge(ws) W^T (+ residual), merge = the combine of the split states (the bits dllm_attn_decode writes to `out`), computed while
+ * every block stages x: one launch per layer and token fewer.  ws fp32 [M * H][nsplit][D + 2]; W [N][ldw], K = H * D; M <= 4. */
+int dllm_gemv_attn_combine(const float* ws, const void* W, void* y, const void* residual, int M, int H, int D, int nsplit, int64_t N,
+                           int64_t ldw, int64_t ldy, int64_t ldr, int out_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------- test probes
  * hardware-convention probes used by tests/test_kernels_gpu.py (ds_read_b64_tr_b16 and MFMA 16x16x32 fragment layouts) */

@@ -1199,3 +1199,26 @@ def test_gemm_rope_qkv_equals_gemm_plus_rope(M, Hq, Hkv, K, with_pos):
     ref_r = ref.clone()
     ref_r[:, : Hq + Hkv] = (ref * c + rot * s_)[:, : Hq + Hkv]
     assert rel_l2(y.view(M, -1, D), ref_r) < 6e-3
+
+
+@pytest.mark.parametrize("B,H,Hkv,D,Smax,lens,nsplit", [(1, 32, 32, 128, 640, [514], 8), (2, 8, 2, 128, 300, [37, 300], 4), (3, 4, 4, 64, 128, [1, 64, 128], 8)])
+def test_gemv_attn_combine_equals_combine_then_gemv(B, H, Hkv, D, Smax, lens, nsplit):
+    """round 6: the o projection fed with the split-KV partials (dllm_gemv_attn_combine after dllm_attn_decode_rope with out = NULL) ==
+    attention with its combine launch followed by dllm_gemv_bf16, bit for bit (residual included)."""
+    ops = _ops()
+    from oracle import llm_ref
+    torch.manual_seed(B + H + D + Smax)
+    q, kn, vn = rnd(B, H, D).to(DEV), rnd(B, Hkv, D).to(DEV), rnd(B, Hkv, D).to(DEV)
+    kc, vc = rnd(B, Smax, Hkv, D).to(DEV), rnd(B, Smax, Hkv, D).to(DEV)
+    kv_len = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    pos = (kv_len.long() - 1)
+    cos, sin = llm_ref.rope_tables(D, Smax + 1)
+    ct, st = cos[:, : D // 2].contiguous().to(DEV), sin[:, : D // 2].contiguous().to(DEV)
+    w, res = rnd(320, H * D, scale=(H * D) ** -0.5).to(DEV), rnd(B, 320).to(DEV)
+    kc2, vc2 = kc.clone(), vc.clone()
+    o = ops.attn_decode_rope(q, kn, vn, kc, vc, kv_len, ct, st, pos, nsplit=nsplit)
+    y0 = ops.gemv(o.view(B, H * D), w, residual=res)
+    ws = ops.attn_decode_rope(q, kn, vn, kc2, vc2, kv_len, ct, st, pos, nsplit=nsplit, partials_only=True)
+    y1 = ops.gemv_attn_combine(ws, w, B, H, D, nsplit, residual=res)
+    assert y1 is not None and torch.equal(y0, y1)
+    assert torch.equal(kc, kc2) and torch.equal(vc, vc2)      # the cache append is unchanged
