@@ -1296,6 +1296,19 @@ static inline double tile_cost_us(int64_t M, int64_t N, int64_t K, int TM, int T
     return (double)cdiv64(tiles, slots) * (fixed + (double)K / 64.0 * perk);
 }
 
+// The LDS-DMA kernels address their dense operands with a buffer descriptor per K tile and 32-bit per-lane byte offsets (round 6): a tile's
+// rows (k-contiguous image: 256 rows of ld elements; m-contiguous image: 64 k rows of ld elements + the column) must span less than 2 GiB.
+// Operands with larger leading dimensions (strided views of huge buffers) take the register-staged kernels.
+template <int AL, int BL>
+static inline bool pipe_offsets_ok(const GemmParams& P) {
+    constexpr int64_t kLim = ((int64_t)1 << 31) - 4096;
+    if (AL == A_K && 256 * P.lda * 2 >= kLim) return false;
+    if (AL == A_M && (64 * P.lda + P.M) * 2 >= kLim) return false;
+    if (BL == B_K && 256 * P.ldb * 2 >= kLim) return false;
+    if (BL == B_N && (64 * P.ldb + P.N) * 2 >= kLim) return false;
+    return true;
+}
+
 // The ring-buffered 128 x 128 kernel (gemm_ring.hip) replaces the register-staged 128-tile kernel wherever it is eligible: forward
 // linears and NHWC convs with K % 64 == 0 (conv: C % 64 == 0), with or without split-K (separate reduce launch only).
 template <int AL, int BL>
@@ -1329,14 +1342,14 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
         return dllm_launch_gemm_ring(Q, AL, stream, V.ring_stages);
     }
     if constexpr (AL == A_K && BL == B_K) {
-        if ((V.force_mfma32 || V.force_w4) && (P.M % 256) == 0 && (P.N % 256) == 0 && (P.K % BK) == 0 && P.K >= BK && !P.out_f32 && P.bias == nullptr &&
+        if ((V.force_mfma32 || V.force_w4) && pipe_offsets_ok<AL, BL>(P) && (P.M % 256) == 0 && (P.N % 256) == 0 && (P.K % BK) == 0 && P.K >= BK && !P.out_f32 && P.bias == nullptr &&
             P.residual == nullptr && P.rg_bias == nullptr && P.epi == 0 && !P.accumulate && P.splitk <= 1 && (P.ldc & 7) == 0 &&
             (reinterpret_cast<uintptr_t>(P.C) & 15) == 0)
             return V.force_w4 ? dllm_launch_gemm_w4(P, stream) : dllm_launch_gemm_pipe32(P, stream);
     }
     ring = ring && V.force_tile == 0 && !V.no_ring;   // tile codes 128 / 256 / 257 / 259 keep selecting the older families (tests)
     const int64_t tiles256 = cdiv64(P.M, 256) * cdiv64(P.N, 256);
-    bool glds_ok = V.use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K);
+    bool glds_ok = V.use_glds && (P.K % BK) == 0 && P.K >= BK && !(AL == A_M && BL == B_K) && pipe_offsets_ok<AL, BL>(P);
     if (AL == A_CONV)  // LDS-DMA gather: plain geometry, a K tile inside one tap, pipelined kernel only
         glds_ok = glds_ok && V.glds_pipe && (P.cv.C % BK) == 0 && BL == B_K;
     // relative speeds: register-staged 128-tile 0.85 (two blocks per CU), ring 128-tile 1.0 (one block per CU), register-staged
@@ -1544,6 +1557,7 @@ int dllm_gemm_swiglu_fwd(const void* x, const void* wgu, void* gu, void* act, in
                          int64_t ldgu, int64_t ldact, int group_m, void* stream) {
     if (M <= 0 || F <= 0 || K < BK || (M % 256) || (F % 128) || (K % BK)) return DLLM_ERR_SHAPE;
     if (!aligned16(x) || !aligned16(wgu) || !aligned16(gu) || !aligned16(act) || ((ldx | ldw | ldgu | ldact) & 7)) return DLLM_ERR_ALIGN;
+    if (256 * ldx * 2 >= ((int64_t)1 << 31) - 4096 || (F + 256) * ldw * 2 >= ((int64_t)1 << 31) - 4096) return DLLM_ERR_SHAPE;   // 32-bit DMA offsets
     GemmParams P{};
     P.A = (const bf16*)x; P.B = (const bf16*)wgu; P.C = gu; P.aux_out = (bf16*)act;
     P.M = M; P.N = 2 * F; P.K = K; P.lda = ldx; P.ldb = ldw; P.ldc = ldgu; P.ld_aux_out = ldact; P.glu_F = F;
@@ -1565,6 +1579,7 @@ int dllm_gemm_rope_qkv(const void* x, const void* wqkv, void* qkv, const float* 
     if (M <= 0 || N <= 0 || K < BK || (M % 256) || (N % 256) || (K % BK) || rope_cols <= 0 || rope_cols > N || (rope_cols % 256) || S <= 0) return DLLM_ERR_SHAPE;
     if (cos_tab == nullptr || sin_tab == nullptr) return DLLM_ERR_SHAPE;
     if (!aligned16(x) || !aligned16(wqkv) || !aligned16(qkv) || !aligned16(cos_tab) || !aligned16(sin_tab) || ((ldx | ldw | ldo) & 7)) return DLLM_ERR_ALIGN;
+    if (256 * ldx * 2 >= ((int64_t)1 << 31) - 4096 || 256 * ldw * 2 >= ((int64_t)1 << 31) - 4096) return DLLM_ERR_SHAPE;   // 32-bit DMA offsets
     GemmParams P{};
     P.A = (const bf16*)x; P.B = (const bf16*)wqkv; P.C = qkv;
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldb = ldw; P.ldc = ldo;
@@ -1582,6 +1597,7 @@ int dllm_gemm_swiglu_bwd(const void* dy, const void* wd, const void* gu, void* d
                          int64_t ldw, int64_t ldgu, int64_t lddgu, int group_m, void* stream) {
     if (M <= 0 || F <= 0 || D < BK || (M % 256) || (F % 256) || (D % BK)) return DLLM_ERR_SHAPE;
     if (!aligned16(dy) || !aligned16(wd) || !aligned16(gu) || !aligned16(dgu) || ((lddy | ldw | ldgu | lddgu) & 7)) return DLLM_ERR_ALIGN;
+    if (256 * lddy * 2 >= ((int64_t)1 << 31) - 4096 || (64 * ldw + F) * 2 >= ((int64_t)1 << 31) - 4096) return DLLM_ERR_SHAPE;   // 32-bit DMA offsets
     GemmParams P{};
     P.A = (const bf16*)dy; P.B = (const bf16*)wd; P.C = dgu; P.aux_in = (const bf16*)gu;
     P.M = M; P.N = F; P.K = D; P.lda = lddy; P.ldb = ldw; P.ldc = lddgu; P.ld_aux_in = ldgu; P.glu_F = F;

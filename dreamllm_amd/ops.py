@@ -419,6 +419,13 @@ def linear_geglu(x, w, bias=None):
 FUSED_SWIGLU = os.environ.get("DREAMLLM_FUSED_SWIGLU", "1") != "0"
 
 
+_DMA_LIM = (1 << 31) - 4096   # the LDS-DMA kernels address a tile's rows with 32-bit byte offsets (csrc/gemm.hip pipe_offsets_ok)
+
+
+def _ld_too_wide(ld):
+    return 256 * int(ld) * 2 >= _DMA_LIM
+
+
 def _glu_group_m(layout, M, N, K):
     return _group_m_for(layout[0], layout[1], M, N, K)
 
@@ -432,7 +439,7 @@ def linear_swiglu_fwd(x, wgu):
     M, K = x2.shape
     F2 = wgu.shape[0]
     F_ = F2 // 2
-    if M % 256 or F_ % 128 or K % 64 or K < 64 or not wgu.is_contiguous():
+    if M % 256 or F_ % 128 or K % 64 or K < 64 or not wgu.is_contiguous() or _ld_too_wide(x2.stride(0)) or (F_ + 256) * K * 2 >= _DMA_LIM:
         return None
     _need_gpu(x2, wgu)
     _bf16(x2, wgu)
@@ -457,7 +464,8 @@ def linear_rope_qkv(x, wqkv, cos, sin, pos, n_rot_heads, head_dim, S):
     M, K = x2.shape
     N = wqkv.shape[0]
     rope_cols = n_rot_heads * head_dim
-    if M % 256 or N % 256 or rope_cols % 256 or rope_cols > N or K % 64 or K < 64 or not wqkv.is_contiguous():
+    if M % 256 or N % 256 or rope_cols % 256 or rope_cols > N or K % 64 or K < 64 or not wqkv.is_contiguous() or _ld_too_wide(x2.stride(0)) \
+            or _ld_too_wide(K):
         return None
     if cos.dtype != torch.float32 or sin.dtype != torch.float32 or cos.shape[-1] != 64 or not cos.is_contiguous() or not sin.is_contiguous():
         return None
@@ -485,6 +493,8 @@ def linear_dgrad_swiglu(dy, wd, gu, dgu=None):
     M, D = d2.shape
     F_ = wd.shape[1]
     if M % 256 or F_ % 256 or D % 64 or D < 64 or not wd.is_contiguous() or gu.shape != (M, 2 * F_) or gu.stride(1) != 1 or gu.stride(0) % 8:
+        return None
+    if _ld_too_wide(d2.stride(0)) or (64 * F_ + F_) * 2 >= _DMA_LIM:
         return None
     _need_gpu(d2, wd, gu)
     _bf16(d2, wd, gu)

@@ -1222,3 +1222,23 @@ def test_gemv_attn_combine_equals_combine_then_gemv(B, H, Hkv, D, Smax, lens, ns
     y1 = ops.gemv_attn_combine(ws, w, B, H, D, nsplit, residual=res)
     assert y1 is not None and torch.equal(y0, y1)
     assert torch.equal(kc, kc2) and torch.equal(vc, vc2)      # the cache append is unchanged
+
+
+def test_gemm_huge_leading_dimension_takes_the_64bit_kernels():
+    """The LDS-DMA kernels address a tile's rows with 32-bit byte offsets from a per-tile descriptor (round 6): 256 rows x ld x 2 bytes must
+    stay below 2 GiB.  A strided view with ld = 2^23 elements (4 GiB per 256 rows) has to take the register-staged kernels -- same results,
+    not zeros from an out-of-range descriptor offset."""
+    ops = _ops()
+    M, K, N, ld = 512, 256, 512, 1 << 23
+    torch.manual_seed(9)
+    buf = torch.zeros((M - 1) * ld + K, dtype=BF, device=DEV)      # 8.6 GB
+    xs = torch.as_strided(buf, (M, K), (ld, 1))
+    xc = rnd(M, K).to(DEV)
+    xs.copy_(xc)
+    w = rnd(N, K, scale=K ** -0.5).to(DEV)
+    y = ops.linear_fwd(xs, w)
+    assert rel_l2(y, xc.float().cpu() @ w.float().cpu().t()) < 4e-3
+    with ops.gemm_variant(259):
+        y259 = ops.linear_fwd(xs, w)
+    assert torch.equal(y259, ops.linear_fwd(xc, w)) or rel_l2(y259, ops.linear_fwd(xc, w).float()) < 2e-3
+    assert ops.linear_swiglu_fwd(xs, rnd(2 * 256, K).to(DEV)) is None     # the fused wrappers decline (the caller runs the unfused launches)
