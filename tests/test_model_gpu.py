@@ -575,6 +575,10 @@ def test_ragged_batch_on_compact_rows_matches_the_padded_grid():
 
     l0, g0 = run(False)
     l1, g1 = run(True)
+    m.gradient_checkpointing_enable()          # whole-layer recompute on compact rows: the same bits as keeping them
+    l2, g2 = run(True)
+    m.gradient_checkpointing_disable()
+    assert l2 == l1 and all(torch.equal(g1[n], g2[n]) for n in g1)
     assert abs(l0 - l1) <= 2e-3 * abs(l0), (l0, l1)
     assert g0.keys() == g1.keys()
     worst = max(((g0[n] - g1[n]).norm() / (g0[n].norm() + 1e-12)).item() for n in g0)
