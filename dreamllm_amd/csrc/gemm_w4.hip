@@ -37,10 +37,14 @@ __device__ __forceinline__ void w4_frag(u32x4& f, uint32_t base) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(a), "n"(IDX * 4096));
 }
 
-// wait for the 8 fragment reads of a k step (a function, not a statement inside the generic lambdas below: inline-asm operands there do
-// not count as captures)
+// counted wait for the 8 fragment reads of a k step: at most N younger LDS reads may still be outstanding (a function, not a statement
+// inside the generic lambdas below: inline-asm operands there do not count as captures)
+template <int N>
 __device__ __forceinline__ void w4_wait(u32x4 (&a)[4], u32x4 (&b)[4]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : : "memory");
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])
+                 : "n"(N)
+                 : "memory");
 }
 
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams P) {
@@ -92,6 +96,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams P) {
     __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)curA, 0, 0x7fffffff, 0x00020000);
     __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)curB, 0, 0x7fffffff, 0x00020000);
     auto advance = [&]() {   // descriptors of the next K tile
+#if defined(W4_DIAG) && W4_DIAG == 2
+        return;              // diagnostic: every K tile re-reads tile 0 (all cache hits; wrong results)
+#endif
         curA += BK * 2;
         curB += BK * 2;
         rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)curA, 0, 0x7fffffff, 0x00020000);
@@ -99,6 +106,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams P) {
     };
     // request q (0-7: A groups, 8-15: B groups) of the tile rsA / rsB point at, into stage `buf`
     auto request = [&](int buf, int q) {
+#if defined(W4_DIAG) && W4_DIAG == 1
+        if (buf >= 0) return;   // diagnostic: no requests at all (the MFMA + fragment-read + barrier stream alone; wrong results)
+#endif
         char* st = smem + buf * W4_STAGE;
         if (q < 8)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave * 8 + q) * 1024), 16, (int)voA[q], 0, 0, 0);
@@ -110,60 +120,77 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams P) {
     const uint32_t s0 = lds_addr(smem);
     const uint32_t offA = (uint32_t)kc_off(wm + (lane & 31), lane >> 5);
     const uint32_t offB = (uint32_t)W4_TILE + (uint32_t)kc_off(wn + (lane & 31), lane >> 5);
-    u32x4 fa[2][4], fb[2][4];   // fragments of the current / the next k step
+    u32x4 fa[4][4], fb[4][4];   // the fragments of a whole K tile, one set per 16-deep k step
 
     const int nt = (int)(P.K / BK);
-    // ---- prologue: tile 0 lands, tile 1's A half is requested, the fragments of (tile 0, k step 0) are read
+    // ---- prologue: tiles 0 and 1 requested, tile 0 lands, the fragments of its k steps 0 and 1 are read
 #pragma unroll
     for (int q = 0; q < 16; ++q) request(0, q);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     if (nt > 1) {
         advance();
 #pragma unroll
-        for (int q = 0; q < 8; ++q) request(1, q);
+        for (int q = 0; q < 16; ++q) request(1, q);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_s_barrier();
     {
         const uint32_t ab = s0 + offA, bb = s0 + offB;
         static_for<0, 4>([&fa, ab](auto i) { w4_frag<decltype(i)::value, 0>(fa[0][decltype(i)::value], ab); });
         static_for<0, 4>([&fb, bb](auto j) { w4_frag<decltype(j)::value, 0>(fb[0][decltype(j)::value], bb); });
+        static_for<0, 4>([&fa, ab](auto i) { w4_frag<decltype(i)::value, 1>(fa[1][decltype(i)::value], ab); });
+        static_for<0, 4>([&fb, bb](auto j) { w4_frag<decltype(j)::value, 1>(fb[1][decltype(j)::value], bb); });
     }
 
-    // One K tile.  HAS1: a tile t + 1 follows (its requests 8-15 ride on k step 0, the tile barrier + its first fragment reads on k step 3);
-    // HAS2: a tile t + 2 follows (its requests 0-7 ride on k step 3, behind the barrier that frees this tile's stage).
+    // One K tile = 64 MFMAs, g = 16 ks + n; a wave enters with the fragments of k steps 0 and 1 requested.
+    //   g  0-15   read the A fragments of k steps 2, 3 (g 0-7), then the B fragments (g 8-15): by g 32 the whole tile is in registers
+    //   g 16      barrier: the A half of stage cb is free; g 24: barrier: the B half is free -- HALF A TILE before its MFMAs end
+    //   g 16 + 3r request r of tile t + 2 into stage cb (r 0-7 the A groups, 8-15 the B groups): ONE request per three MFMAs per wave =
+    //             64 requests of 1 KiB per 2048 clk for the CU -- the vector L1 moves 64 B/clk, i.e. at most one request per 16 clk, so
+    //             eight requests per wave inside 256 clk (the first form of this kernel) queue the four waves behind one another
+    //   g 48      tile t + 1 (requested at g 16-61 of the tile before: 0.8-1.5 K tiles of MFMA time ago) has landed: counted vmcnt (the
+    //             11 requests of tile t + 2 issued so far may be out), barrier, read the fragments of its k steps 0 (g 48-55), 1 (g 56-63)
+    // HAS1: a tile t + 1 follows; HAS2: a tile t + 2 follows.
     auto body = [&](int t, auto has1_c, auto has2_c) {
         constexpr bool HAS1 = decltype(has1_c)::value, HAS2 = decltype(has2_c)::value;
         const int cb = t & 1, nb = cb ^ 1;
         const uint32_t ab = s0 + offA + (uint32_t)(cb * W4_STAGE), bb = s0 + offB + (uint32_t)(cb * W4_STAGE);
         const uint32_t abn = s0 + offA + (uint32_t)(nb * W4_STAGE), bbn = s0 + offB + (uint32_t)(nb * W4_STAGE);
         static_for<0, 4>([&](auto ksc) {
-            constexpr int ks = decltype(ksc)::value, p = ks & 1;
-            // the 8 fragments of this k step were requested behind the first 8 MFMAs of the step before: they have had >= 8 MFMAs to land
-            w4_wait(fa[p], fb[p]);
-            if constexpr (ks == 3 && HAS1) {
-                // this wave's last reads of stage cb are in registers and its share of tile t + 1 has landed: behind the barrier stage cb
-                // is free for tile t + 2 and stage nb is readable
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if constexpr (HAS2) advance();
-            }
+            constexpr int ks = decltype(ksc)::value;
             static_for<0, 16>([&](auto nc) {
-                constexpr int n = decltype(nc)::value, i = n >> 2, j = n & 3;
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[p][j]), __builtin_bit_cast(bf16x8, fa[p][i]), acc[i][j], 0, 0, 0);
-                // ---- the filler behind MFMA n
-                if constexpr (n < 8) {   // fragment n of the next k step (k step 0 of tile t + 1 behind the barrier)
-                    if constexpr (ks < 3) {
-                        if constexpr (n < 4) w4_frag<n, ks + 1>(fa[p ^ 1][n], ab);
-                        else w4_frag<n - 4, ks + 1>(fb[p ^ 1][n - 4], bb);
-                    } else if constexpr (HAS1) {
-                        if constexpr (n < 4) w4_frag<n, 0>(fa[p ^ 1][n], abn);
-                        else w4_frag<n - 4, 0>(fb[p ^ 1][n - 4], bbn);
+                constexpr int n = decltype(nc)::value, i = n >> 2, j = n & 3, g = ks * 16 + n;
+                if constexpr (g == 0) w4_wait<8>(fa[0], fb[0]);     // k step 1's eight reads may still be out
+                if constexpr (g == 16) {
+                    w4_wait<8>(fa[1], fb[1]);                        // ... and the A reads of k steps 2, 3 are in; the B reads may be out
+                    if constexpr (HAS2) {
+                        __builtin_amdgcn_s_barrier();                // every wave has read the A half of stage cb
+                        advance();
                     }
-                } else {
-                    // (all 16 requests of tile t + 2 behind the 16 MFMAs of k step 3 -- three k steps to land instead of two -- measured the
-                    // same: 1291 vs 1286 TF on the packed gate|up forward, profiles/r06_gemm_w4_clock.log)
-                    if constexpr (ks == 0 && HAS1) request(nb, n);                  // requests 8-15 (B) of tile t + 1
-                    if constexpr (ks == 3 && HAS2) request(cb, n - 8);              // requests 0-7 (A) of tile t + 2 into the stage just freed
+                }
+                if constexpr (g == 24) {
+                    w4_wait<0>(fa[2], fb[2]);
+                    w4_wait<0>(fa[3], fb[3]);
+                    if constexpr (HAS2) __builtin_amdgcn_s_barrier();   // ... and the B half
+                }
+                if constexpr (g == 48 && HAS1) {
+                    if constexpr (HAS2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                    // every wave's share of tile t + 1 is in stage nb
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[ks][j]), __builtin_bit_cast(bf16x8, fa[ks][i]), acc[i][j], 0, 0, 0);
+                // ---- the fillers behind MFMA g
+                if constexpr (g < 4) w4_frag<g, 2>(fa[2][g], ab);
+                else if constexpr (g < 8) w4_frag<g - 4, 3>(fa[3][g - 4], ab);
+                else if constexpr (g < 12) w4_frag<g - 8, 2>(fb[2][g - 8], bb);
+                else if constexpr (g < 16) w4_frag<g - 12, 3>(fb[3][g - 12], bb);
+                if constexpr (HAS2 && g >= 16 && (g - 16) % 3 == 0 && (g - 16) / 3 < 16) request(cb, (g - 16) / 3);
+                if constexpr (HAS1 && g >= 48) {
+                    if constexpr (g < 52) w4_frag<g - 48, 0>(fa[0][g - 48], abn);
+                    else if constexpr (g < 56) w4_frag<g - 52, 0>(fb[0][g - 52], bbn);
+                    else if constexpr (g < 60) w4_frag<g - 56, 1>(fa[1][g - 56], abn);
+                    else w4_frag<g - 60, 1>(fb[1][g - 60], bbn);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
