@@ -22,6 +22,7 @@
 // swapped (D^T = B^T A^T) so every lane ends up with 4 consecutive output columns of one row -> 8/16-byte stores.
 // blockIdx is remapped so each XCD (private 4 MiB L2) works on a contiguous group of tiles (GROUP_M swizzle).
 #include "gemm_shared.h"
+#include "gemm_epilogues.h"
 
 namespace {
 
@@ -42,12 +43,14 @@ struct Variant {
     int no_ring = 0;     // bit 25: never pick the ring-buffered kernel by itself (the round-3 selection: A/B knob of tools / bench)
     int dma_mode = -1;     // bench builds: tile codes 271-276, placement of the ring kernel's LDS-DMA requests (experiment)
     int force_mfma32 = 0;  // tile code 266: the MFMA 32x32x16 experiment (gemm_mfma32.hip) wherever it is eligible (tools)
-    int force_w4 = 0;      // tile code 261: the four-wave experiment (gemm_w4.hip) wherever it is eligible (tools)
+    int force_w4 = 0;      // tile code 261: the four-wave MFMA 32x32x16 experiment (gemm_w4.hip) wherever it is eligible (tools)
+    int w4m = 0;           // the four-wave 16x16x32 kernel (gemm_w4.hip: gemm_w4m_kernel) instead of gemm_pipe_kernel: 1 = where the launcher
+                           // finds it faster (tile code 0), 2 = wherever it is eligible (tile code 280: tests, tools); 259 keeps the 8-wave kernel
 };
 static inline int parse_variant(int variant, Variant& v) {
     const int tile = variant & 0xffff;
     v.group_m = (variant >> 16) & 0xff;
-    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 261 || tile == 262 || tile == 264 || tile == 266 || tile == 267 || tile == 268;
+    bool ok = tile == 0 || tile == 128 || tile == 256 || tile == 257 || tile == 259 || tile == 261 || tile == 262 || tile == 280 || tile == 264 || tile == 266 || tile == 267 || tile == 268;
 #ifdef DLLM_BENCH_MODES
     ok = ok || tile == 258 || tile == 260 || tile == 263 || tile == 265 || (tile >= 269 && tile <= 279);
     v.dbg_noload = (tile == 258 || tile == 260) ? 1 : (tile == 263 ? 2 : (tile == 265 ? 3 : ((tile >= 269 && tile <= 279) ? 4 : 0)));
@@ -70,6 +73,8 @@ static inline int parse_variant(int variant, Variant& v) {
     v.dma_mode = (tile >= 271 && tile <= 273) ? tile - 270 : ((tile >= 274 && tile <= 276) ? tile - 273 : ((tile == 277 || tile == 278) ? tile - 273 : (tile == 279 ? 0 : -1)));   // -1: the kernel's default; 279: two-stage with one request per MFMA group   // 277: no LDS-DMA in the loop, 278: no MFMAs (ablations, two-stage flag ignored: four-stage)
     v.force_mfma32 = tile == 266;
     v.force_w4 = tile == 261;
+    v.w4m = tile == 280 ? 2 : (tile == 0 ? 1 : 0);
+    if (tile == 280) v.glds_pipe = 1;
     if (v.force_ring) v.force_tile = 0;
     return DLLM_OK;
 }
@@ -857,172 +862,7 @@ __device__ __forceinline__ void pipe_tile(const GemmParams& P, char* smem, int64
     __builtin_amdgcn_s_setprio(0);
 }
 
-// ---- fused SwiGLU epilogues (round 6) ----------------------------------------------------------------------------------------
-// Both keep the arithmetic of the stand-alone kernels (elementwise.hip: glu_fwd_kernel / glu_bwd_kernel) on the SAME bf16-rounded
-// operands, so fused and unfused paths give identical results; what disappears is a launch and its round trip through HBM:
-//   FWD  (gate|up projection): the wave holds gate (acc[i][0..1]) and up (acc[i][2..3]) of 32 outputs x 128 rows; it stores the packed
-//        [M, 2F] gate|up tile the backward reads AND act = silu(gate) * up [M, F] -- glu_fwd (a read of 2 x [M, F] and a launch) is gone;
-//   BWD  (down projection's input gradient): d_act = dy Wd stays in the accumulators; gate / up tiles come in through the wave's LDS
-//        region (row-contiguous 16-byte loads), d gate / d up go out the same way -- the [M, F] d_act tensor (written, then read) and
-//        glu_bwd's launch are gone.
-// Full tiles only (M % 256 == 0; FWD: F % 128 == 0; BWD: F % 256 == 0), 16-byte aligned rows: the entry points check.
-// wl: this wave's LDS region, 16 KiB (two 64-row x 128-byte images, chunk swizzle of gemm_epilogue_lds).
-template <int MI>
-__device__ __forceinline__ void gemm_epilogue_swiglu_fwd(const GemmParams& P, f32x4 (&acc)[MI][4], char* wl, int64_t mw, int64_t n0, int wn,
-                                                         int lane) {
-    bf16* gu = reinterpret_cast<bf16*>(P.C);
-    const int64_t h0 = (n0 >> 1) + (wn >> 6) * 32;   // first of the wave's 32 output columns
-#pragma unroll
-    for (int half = 0; half < MI / 4; ++half) {
-        // pass 1: the packed gate|up tile (64 rows x [32 gate | 32 up]) through the region, rows out as 2 x 64 contiguous bytes
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = half * 4 + ii;
-            const int r = ii * 16 + (lane & 15);
-            const int sw = ((r >> 1) & 7) << 1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)(acc[i][j][e] * P.alpha);
-                *reinterpret_cast<bf16x4*>(wl + r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3)) = o;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + (lane >> 3), p = lane & 7;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(wl + row * 128 + ((p ^ ((row >> 1) & 7)) << 4));
-            st_bf16x8(gu + (mw + half * 64 + row) * P.ldc + ((p & 4) ? P.glu_F : 0) + h0 + (p & 3) * 8, v);
-        }
-        // pass 2: act from the ROUNDED gate / up (what glu_fwd_kernel reads back from memory), 64 rows x 64 bytes
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = half * 4 + ii;
-            const int r = ii * 16 + (lane & 15);
-            const int sw = ((r >> 1) & 7) << 1;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x = (float)(bf16)(acc[i][j][e] * P.alpha), y = (float)(bf16)(acc[i][j + 2][e] * P.alpha);
-                    o[e] = (bf16)(silu_f(x) * y);
-                }
-                *reinterpret_cast<bf16x4*>(wl + 8192 + r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3)) = o;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 16 + (lane >> 2), p = lane & 3;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(wl + 8192 + row * 128 + ((p ^ ((row >> 1) & 7)) << 4));
-            st_bf16x8(P.aux_out + (mw + half * 64 + row) * P.ld_aux_out + h0 + p * 8, v);
-        }
-    }
-}
-
-// EPI_ROPE_QKV: rope_kernel's arithmetic (elementwise.hip) on the bf16-ROUNDED projection, in the epilogue of the packed q|k|v GEMM.
-// The wave holds x1 = dims [32 (wc & 1), +32) of head (wc >> 1) in acc[i][0..1] and x2 = the same dims + 64 in acc[i][2..3] (B rows re-mapped
-// in pipe_tile); y1 = x1 cos - x2 sin, y2 = x2 cos + x1 sin with the fp32 table rows of the token's position.  Identical results to GEMM +
-// dllm_rope; the separate launch and its read + write of the q and k heads are gone.
-template <int MI>
-__device__ __forceinline__ void gemm_epilogue_rope(const GemmParams& P, f32x4 (&acc)[MI][4], char* wl, int64_t mw, int64_t n0, int wn, int lane) {
-    bf16* C = reinterpret_cast<bf16*>(P.C);
-    const int wc = wn >> 6;
-    const int64_t c0 = n0 + (wc >> 1) * 128 + (wc & 1) * 32;   // output column of the wave's first x1 dim
-    const int d0 = (wc & 1) * 32 + (lane >> 4) * 4;             // the lane's first dim (of the 64 pair dims) for j = 0
-#pragma unroll
-    for (int half = 0; half < MI / 4; ++half) {
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = half * 4 + ii;
-            const int r = ii * 16 + (lane & 15);
-            const int sw = ((r >> 1) & 7) << 1;
-            const int64_t m = mw + i * 16 + (lane & 15);
-            const int64_t p = P.rope_pos ? P.rope_pos[m] : (m % P.rope_S);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x4 cc = *reinterpret_cast<const f32x4*>(P.rope_cos + p * 64 + d0 + j * 16);
-                const f32x4 ss = *reinterpret_cast<const f32x4*>(P.rope_sin + p * 64 + d0 + j * 16);
-                bf16x4 o1, o2;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float y1, y2;
-                    rope_pair((float)(bf16)(acc[i][j][e] * P.alpha), (float)(bf16)(acc[i][j + 2][e] * P.alpha), cc[e], ss[e], y1, y2);
-                    o1[e] = (bf16)y1;
-                    o2[e] = (bf16)y2;
-                }
-                *reinterpret_cast<bf16x4*>(wl + r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3)) = o1;
-                *reinterpret_cast<bf16x4*>(wl + r * 128 + ((((j + 2) * 4 + (lane >> 4)) ^ sw) << 3)) = o2;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + (lane >> 3), p = lane & 7;
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(wl + row * 128 + ((p ^ ((row >> 1) & 7)) << 4));
-            st_bf16x8(C + (mw + half * 64 + row) * P.ldc + c0 + ((p & 4) ? 64 : 0) + (p & 3) * 8, v);
-        }
-    }
-}
-
-template <int MI>
-__device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmParams& P, f32x4 (&acc)[MI][4], char* wl, int64_t mw, int64_t nw, int lane) {
-    bf16* dgu = reinterpret_cast<bf16*>(P.C);
-    char* w0 = wl;            // gate in, d gate out
-    char* w1 = wl + 8192;     // up in, d up out
-#pragma unroll
-    for (int half = 0; half < MI / 4; ++half) {
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + (lane >> 3), p = lane & 7;
-            const bf16* src = P.aux_in + (mw + half * 64 + row) * P.ld_aux_in + nw + p * 8;
-            const int off = row * 128 + ((p ^ ((row >> 1) & 7)) << 4);
-            *reinterpret_cast<bf16x8*>(w0 + off) = ld_bf16x8(src);
-            *reinterpret_cast<bf16x8*>(w1 + off) = ld_bf16x8(src + P.glu_F);
-        }
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int i = half * 4 + ii;
-            const int r = ii * 16 + (lane & 15);
-            const int sw = ((r >> 1) & 7) << 1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int off = r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3);
-                const bf16x4 gv = *reinterpret_cast<const bf16x4*>(w0 + off), uv = *reinterpret_cast<const bf16x4*>(w1 + off);
-                bf16x4 oa, ob;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {   // glu_bwd_kernel<0>, on d_act rounded to bf16 as the unfused path stores it
-                    const float d = (float)(bf16)(acc[i][j][e] * P.alpha), x = (float)gv[e], y = (float)uv[e];
-                    const float sg = sigmoid_f(x);
-                    const float act = x * sg;
-                    const float dact = sg * (1.f + x * (1.f - sg));
-                    oa[e] = (bf16)(d * y * dact);
-                    ob[e] = (bf16)(d * act);
-                }
-                *reinterpret_cast<bf16x4*>(w0 + off) = oa;
-                *reinterpret_cast<bf16x4*>(w1 + off) = ob;
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + (lane >> 3), p = lane & 7;
-            const int off = row * 128 + ((p ^ ((row >> 1) & 7)) << 4);
-            bf16* dst = dgu + (mw + half * 64 + row) * P.ldc + nw + p * 8;
-            st_bf16x8(dst, *reinterpret_cast<const bf16x8*>(w0 + off));
-            st_bf16x8(dst + P.glu_F, *reinterpret_cast<const bf16x8*>(w1 + off));
-        }
-    }
-}
-
-// Tile `wgid` of the grouped (GROUP_M) tile order -> (pid_m, pid_n)
-__device__ __forceinline__ void pipe_decode_tile(const GemmParams& P, int wgid, int num_pid_m, int num_pid_n, int& pid_m, int& pid_n) {
-    const int GROUP_M = P.group_m > 0 ? P.group_m : 8;
-    const int in_group = GROUP_M * num_pid_n;
-    const int group_id = wgid / in_group;
-    const int first_m = group_id * GROUP_M;
-    const int gsz = min(num_pid_m - first_m, GROUP_M);
-    pid_m = first_m + (wgid % in_group) % gsz;
-    pid_n = (wgid % in_group) / gsz;
-}
+// (the fused SwiGLU / RoPE epilogues and pipe_decode_tile live in gemm_epilogues.h: gemm_w4.hip shares them)
 
 template <int AL, int BL, int BN_ = 256>
 __global__ __launch_bounds__(512, 2) void gemm_pipe_kernel(GemmParams P) {
@@ -1460,8 +1300,13 @@ int launch_gemm(const GemmParams& P, const Variant& V, hipStream_t stream) {
                     // XCD-synchronised persistent walk (opt-in, variant bit 24): grids of at least 4 rounds, workspace present
                     static std::atomic<uint64_t> lds4_ok{0};
                     const bool persist = V.persist && V.streamk_ws && P.ws != nullptr && P.splitk <= 1 && P.dbg_noload == 0 && tiles256 >= 1024;
+                    // the four-wave kernel (gemm_w4.hip) takes the grids of at least one full round of 256 tiles (the LLM's linears; tile
+                    // code 280: any grid); same tile order, same arithmetic, same epilogues
+                    const bool w4m = !persist && dllm_w4m_eligible(P, AL, BL) && (V.w4m == 2 || (V.w4m == 1 && tiles256 >= 256));
                     auto launch_main = [&](const GemmParams& Q, int64_t ntiles) {
-                        if (persist) {
+                        if (w4m) {
+                            (void)dllm_launch_gemm_w4m(Q, AL, BL, ntiles, stream);
+                        } else if (persist) {
                             dllm_ensure_dyn_lds(&gemm_pipe_persist_kernel<AL, BL>, LDS, lds4_ok);
                             hipLaunchKernelGGL((gemm_pipe_persist_kernel<AL, BL>), dim3((unsigned)dllm_num_cus()), dim3(512), LDS, stream, Q);
                         } else {
@@ -1548,6 +1393,12 @@ int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bia
     return DLLM_ERR_SHAPE;
 }
 
+// Fused entry points: bits 8-9 of `group_m` choose the kernel family (0: the launcher's choice -- the four-wave kernel from one full round of
+// tiles on; 1: the 8-wave kernel; 2: the four-wave kernel), bits 0-7 are GROUP_M (tools / tests; same results either way)
+static inline bool fused_use_w4m(int group_m, int64_t tiles, const GemmParams& P, int la, int lb) {
+    const int fam = (group_m >> 8) & 3;
+    return fam != 1 && (fam == 2 || tiles >= 256) && dllm_w4m_eligible(P, la, lb);
+}
 // DreamLLMMLP (modeling_dreamllm.py:237) with the SwiGLU folded into the two GEMMs beside it (see gemm_epilogue_swiglu_*).
 //   fwd: gu[M, 2F] = x Wgu^T (Wgu = packed [gate rows; up rows], [2F, K]) and act[M, F] = silu(gu[:, :F]) * gu[:, F:], one launch.
 //   bwd: dgu[M, 2F] = glu_bwd(dy Wd, gu) with Wd [D, F] (the down projection's nn.Linear weight), d_act never stored.
@@ -1561,9 +1412,10 @@ int dllm_gemm_swiglu_fwd(const void* x, const void* wgu, void* gu, void* act, in
     GemmParams P{};
     P.A = (const bf16*)x; P.B = (const bf16*)wgu; P.C = gu; P.aux_out = (bf16*)act;
     P.M = M; P.N = 2 * F; P.K = K; P.lda = ldx; P.ldb = ldw; P.ldc = ldgu; P.ld_aux_out = ldact; P.glu_F = F;
-    P.epi = EPI_SWIGLU_FWD; P.alpha = 1.f; P.splitk = 1; P.group_m = group_m > 0 ? group_m : 4;
+    P.epi = EPI_SWIGLU_FWD; P.alpha = 1.f; P.splitk = 1; P.group_m = (group_m & 0xff) > 0 ? (group_m & 0xff) : 4;
     const int64_t tiles = (M / 256) * (2 * F / 256);
     if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+    if (fused_use_w4m(group_m, tiles, P, A_K, B_K)) return dllm_launch_gemm_w4m(P, A_K, B_K, tiles, (hipStream_t)stream);
     constexpr int LDS = 2 * 2 * 256 * BK * 2;
     static std::atomic<uint64_t> lds_ok{0};
     dllm_ensure_dyn_lds(&gemm_pipe_kernel<A_K, B_K>, LDS, lds_ok);
@@ -1584,9 +1436,10 @@ int dllm_gemm_rope_qkv(const void* x, const void* wqkv, void* qkv, const float* 
     P.A = (const bf16*)x; P.B = (const bf16*)wqkv; P.C = qkv;
     P.M = M; P.N = N; P.K = K; P.lda = ldx; P.ldb = ldw; P.ldc = ldo;
     P.rope_cos = cos_tab; P.rope_sin = sin_tab; P.rope_pos = pos; P.rope_S = S; P.rope_cols = rope_cols;
-    P.epi = EPI_ROPE_QKV; P.alpha = 1.f; P.splitk = 1; P.group_m = group_m > 0 ? group_m : 4;
+    P.epi = EPI_ROPE_QKV; P.alpha = 1.f; P.splitk = 1; P.group_m = (group_m & 0xff) > 0 ? (group_m & 0xff) : 4;
     const int64_t tiles = (M / 256) * (N / 256);
     if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+    if (fused_use_w4m(group_m, tiles, P, A_K, B_K)) return dllm_launch_gemm_w4m(P, A_K, B_K, tiles, (hipStream_t)stream);
     constexpr int LDS = 2 * 2 * 256 * BK * 2;
     static std::atomic<uint64_t> lds_ok{0};
     dllm_ensure_dyn_lds(&gemm_pipe_kernel<A_K, B_K>, LDS, lds_ok);
@@ -1601,9 +1454,10 @@ int dllm_gemm_swiglu_bwd(const void* dy, const void* wd, const void* gu, void* d
     GemmParams P{};
     P.A = (const bf16*)dy; P.B = (const bf16*)wd; P.C = dgu; P.aux_in = (const bf16*)gu;
     P.M = M; P.N = F; P.K = D; P.lda = lddy; P.ldb = ldw; P.ldc = lddgu; P.ld_aux_in = ldgu; P.glu_F = F;
-    P.epi = EPI_SWIGLU_BWD; P.alpha = 1.f; P.splitk = 1; P.group_m = group_m > 0 ? group_m : 4;
+    P.epi = EPI_SWIGLU_BWD; P.alpha = 1.f; P.splitk = 1; P.group_m = (group_m & 0xff) > 0 ? (group_m & 0xff) : 4;
     const int64_t tiles = (M / 256) * (F / 256);
     if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
+    if (fused_use_w4m(group_m, tiles, P, A_K, B_N)) return dllm_launch_gemm_w4m(P, A_K, B_N, tiles, (hipStream_t)stream);
     constexpr int LDS = 2 * 2 * 256 * BK * 2;
     static std::atomic<uint64_t> lds_ok{0};
     dllm_ensure_dyn_lds(&gemm_pipe_kernel<A_K, B_N>, LDS, lds_ok);

@@ -458,3 +458,7 @@ __attribute__((visibility("hidden"))) int dllm_launch_gemm_ring(const GemmParams
 __attribute__((visibility("hidden"))) int dllm_launch_gemm_pipe32(const GemmParams& P, hipStream_t stream);
 // gemm_w4.hip (round 6 experiment): four waves, one per SIMD, wave tile 128 x 128 on MFMA 32x32x16, buffer-form LDS-DMA; same eligibility
 __attribute__((visibility("hidden"))) int dllm_launch_gemm_w4(const GemmParams& P, hipStream_t stream);
+// gemm_w4.hip: the four-wave 256 x 256 kernel on MFMA 16x16x32 (one wave per SIMD, LDS stage released half a tile early); layouts
+// (A_K, B_K), (A_K, B_N), (A_M, B_N); every epilogue of gemm_pipe_kernel; ntiles = blocks of the grouped tile order to launch
+__attribute__((visibility("hidden"))) bool dllm_w4m_eligible(const GemmParams& P, int layout_a, int layout_b);
+__attribute__((visibility("hidden"))) int dllm_launch_gemm_w4m(const GemmParams& P, int layout_a, int layout_b, int64_t ntiles, hipStream_t stream);

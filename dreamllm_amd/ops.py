@@ -286,7 +286,7 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
     sk = 1 if epi == "geglu" else _splitk_hint(M, N, K, layout_a, layout_b)
     ws = torch.empty(sk * M * N, dtype=torch.float32, device=a.device) if sk > 1 else None
     persist = 0
-    if sk == 1 and (GEMM_VARIANT & 0xffff) in (0, 259):
+    if sk == 1 and (GEMM_VARIANT & 0xffff) in (0, 259, 280):
         if STREAMK and _streamk_hint(M, N, K, layout_a, layout_b):
             ws = _streamk_workspace(a.device)   # the library spreads the last partial round of 256-tiles over the CUs (stream-K tail)
             persist = STREAMK_WS_BIT            # bit 26: "this workspace holds dllm_gemm_streamk_ws_bytes() bytes"
@@ -427,13 +427,17 @@ def _ld_too_wide(ld):
 
 
 def _glu_group_m(layout, M, N, K):
-    return _group_m_for(layout[0], layout[1], M, N, K)
+    """GROUP_M (bits 0-7) and the kernel family (bits 8-9: 0 the library's choice, 1 the 8-wave kernel under `gemm_variant(259)`, 2 the four-wave
+    kernel under `gemm_variant(280)`) of the fused entry points."""
+    fam = {259: 1, 280: 2}.get(GEMM_VARIANT & 0xffff, 0)
+    gm = (GEMM_VARIANT >> 16) & 0xff or _group_m_for(layout[0], layout[1], M, N, K)
+    return (gm & 0xff) | (fam << 8)
 
 
 def linear_swiglu_fwd(x, wgu):
     """(gu, act) = (x wgu^T, silu(gu[:, :F]) * gu[:, F:]) in ONE launch; x [M, K], wgu [2F, K] = packed [gate rows; up rows].
     Returns None for shapes the fused kernel does not take (the caller runs GEMM + glu_fwd)."""
-    if not FUSED_SWIGLU or (GEMM_VARIANT & 0xffff) not in (0, 259):
+    if not FUSED_SWIGLU or (GEMM_VARIANT & 0xffff) not in (0, 259, 280):
         return None
     x2 = _as2d(x)
     M, K = x2.shape
@@ -458,7 +462,7 @@ def linear_rope_qkv(x, wqkv, cos, sin, pos, n_rot_heads, head_dim, S):
     """qkv = x wqkv^T with the rotary embedding applied to the first `n_rot_heads` heads (the q and k heads of the packed q|k|v
     projection) in the GEMM's epilogue (csrc/gemm.hip gemm_epilogue_rope): the same results as `linear_fwd` + `rope_`, one launch.
     x [M, K]; wqkv [N, K]; cos / sin fp32 [P, 64]; pos int64 [M] or None (position = row % S).  None for shapes it does not take."""
-    if not FUSED_ROPE or (GEMM_VARIANT & 0xffff) not in (0, 259) or head_dim != 128:
+    if not FUSED_ROPE or (GEMM_VARIANT & 0xffff) not in (0, 259, 280) or head_dim != 128:
         return None
     x2 = _as2d(x)
     M, K = x2.shape
@@ -487,7 +491,7 @@ def linear_rope_qkv(x, wqkv, cos, sin, pos, n_rot_heads, head_dim, S):
 def linear_dgrad_swiglu(dy, wd, gu, dgu=None):
     """d(gate|up) [M, 2F] of act = silu(gate) * up, given dy [M, D] of the down projection (weight wd [D, F]) and the forward's packed
     gate|up buffer: the input gradient d_act = dy wd never leaves the GEMM.  None for shapes the fused kernel does not take."""
-    if not FUSED_SWIGLU or (GEMM_VARIANT & 0xffff) not in (0, 259):
+    if not FUSED_SWIGLU or (GEMM_VARIANT & 0xffff) not in (0, 259, 280):
         return None
     d2 = _as2d(dy)
     M, D = d2.shape

@@ -99,7 +99,10 @@ int64_t dllm_gemm_streamk_ws_bytes(void);
 int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int layout_b);
 /* `variant` selects the kernel PER CALL (the library holds no mutable state; every entry point is re-entrant and may be called
  * from any thread on any stream): low 16 bits = tile family -- 0 automatic (what the product passes), 128 / 256 register-staged
- * tiles, 257 plain LDS-DMA 256-tile kernel, 259 software-pipelined LDS-DMA kernel (the automatic choice for eligible shapes);
+ * tiles, 257 plain LDS-DMA 256-tile kernel, 259 software-pipelined 8-wave LDS-DMA kernel (the automatic choice for eligible shapes of
+ * less than one round of 256 tiles, and for fp32 outputs / ragged edge tiles / NHWC convs), 280 the four-wave kernel of round 6 (one wave
+ * per SIMD, 128 x 128 wave tiles, the LDS stage released half a tile early: the automatic choice from 256 full tiles on, bf16 output;
+ * same bits as 259; ineligible calls fall back to 259);
  * 264 the ring-buffered 128 x 128 kernel for small grids (forward linears / NHWC convs with K % 64 == 0; the automatic choice
  * wherever the register-staged 128-tile kernel used to run; ineligible calls fall back to the automatic choice), 267 / 268 the same
  * kernel forced to its four-stage (one block per CU) / two-stage (two blocks per CU) form; 262 the 256 x 128 pipelined tile; 266 the
@@ -109,7 +112,7 @@ int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int la
  * stream-K workspace of dllm_gemm_streamk_ws_bytes() bytes" -- without it a workspace passed with splitk <= 1 is IGNORED (round 4,
  * round 3 treated any non-NULL workspace as 128 MiB of slab space; a caller re-using its smaller split-K buffer with
  * splitk = 1 would have been written out of bounds); bit 27 = the ring-buffered kernel never takes its two-stage form (A/B knob).
- * Tests pass 128 / 256 / 257 / 259 / 262 / 264 to cover
+ * 261 = the first (MFMA 32x32x16) form of the four-wave kernel, kept as an experiment.  Tests pass 128 / 256 / 257 / 259 / 262 / 264 / 280 to cover
  * every kernel family.  Anything else returns DLLM_ERR_SHAPE.  (A build with -DDLLM_BENCH_MODES additionally accepts the
  * wrong-result diagnostic modes 258 / 260 / 263 / 265 and the ring kernel's timing diagnostics 269-278 (s_memtime stamps of one block written to
  * the workspace, request-placement variants, no-DMA / no-MFMA ablations: tools/ring_timeline.py) used by tools/; the shipped library does not
@@ -125,7 +128,9 @@ int dllm_gemm_bf16_splitk(const void* A, const void* B, void* C, const void* bia
  *        accumulators (replaces the input-gradient GEMM + dllm_glu_bwd).
  * Same arithmetic on the same bf16-rounded operands as the unfused pair: identical results.  M % 256 == 0, K / D % 64 == 0,
  * F % 128 == 0 (fwd) / F % 256 == 0 (bwd), 16-byte aligned pointers, leading dimensions % 8 == 0; otherwise DLLM_ERR_SHAPE / _ALIGN and
- * the caller uses the unfused launches.  group_m: GROUP_M of the grouped tile order (0 = default). */
+ * the caller uses the unfused launches.  group_m: bits 0-7 GROUP_M of the grouped tile order (0 = default); bits 8-9 the kernel family
+ * (0: the library's choice -- the four-wave kernel from one full round of 256 tiles on; 1: the 8-wave kernel; 2: the four-wave kernel;
+ * identical results). */
 int dllm_gemm_swiglu_fwd(const void* x, const void* wgu, void* gu, void* act, int64_t M, int64_t F, int64_t K, int64_t ldx, int64_t ldw,
                          int64_t ldgu, int64_t ldact, int group_m, void* stream);
 int dllm_gemm_swiglu_bwd(const void* dy, const void* wd, const void* gu, void* dgu, int64_t M, int64_t F, int64_t D, int64_t lddy,

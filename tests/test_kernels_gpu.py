@@ -139,7 +139,7 @@ def test_layernorm_fwd_bwd(rows, D):
 
 
 # ----------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=[128, 256, 257, 259, 261, 262, 264, 266])
+@pytest.fixture(params=[128, 256, 257, 259, 261, 262, 264, 266, 280])
 def gemm_tile(request):
     """run the GEMM tests once per block-tile variant (128x128 / 4 waves and 256x256 / 8 waves)"""
     from dreamllm_amd import ops
@@ -1150,15 +1150,17 @@ def test_gemm_swiglu_rejects_what_it_does_not_take():
     assert _lib.call("dllm_gemm_swiglu_fwd", p(a), p(w), p(g), p(o), 200, 128, 64, 64, 64, 256, 128, 0, None) == -1
 
 
+@pytest.mark.parametrize("code", [261, 280])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 192), (1024, 512, 4096), (2048, 2304, 1024)])
-def test_gemm_w4_experiment(M, N, K):
-    """tile code 261: the four-wave 256 x 256 kernel of round 6 (one wave per SIMD, MFMA 32x32x16, buffer-form LDS-DMA; csrc/gemm_w4.hip)
-    against the fp32 oracle, on one, two, three and many K tiles (prologue / steady state / the two peeled tail bodies)."""
+def test_gemm_w4_experiment(M, N, K, code):
+    """tile codes 261 / 280: the four-wave 256 x 256 kernels of round 6 (one wave per SIMD, MFMA 32x32x16 / 16x16x32, buffer-form LDS-DMA, LDS stage
+    released half a tile early; csrc/gemm_w4.hip) against the fp32 oracle, on one, two, three and many K tiles (prologue / steady state / the two
+    peeled tail bodies).  280 adds the products in the order of the 8-wave kernel: the same bits."""
     ops = _ops()
     torch.manual_seed(M + N + K)
     x, w = rnd(M, K), rnd(N, K, scale=K ** -0.5)
     ref = x.float() @ w.float().t()
-    with ops.gemm_variant(261):
+    with ops.gemm_variant(code):
         y = ops.linear_fwd(x.to(DEV), w.to(DEV))
         y2 = ops.linear_fwd(x.to(DEV), w.to(DEV))
     assert rel_l2(y, ref) < 4e-3
@@ -1166,6 +1168,48 @@ def test_gemm_w4_experiment(M, N, K):
     with ops.gemm_variant(259):
         y0 = ops.linear_fwd(x.to(DEV), w.to(DEV))
     assert rel_l2(y, y0.float()) < 3e-3
+    if code == 280 and M * N >= 256 * 256 * 48:    # (smaller grids: 259 hands the shape to another family)
+        assert torch.equal(y, y0)
+
+
+@pytest.mark.parametrize("layout", ["fwd", "dgrad", "wgrad"])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_gemm_w4m_equals_the_8_wave_kernel(layout, ragged):
+    """tile code 280 = gemm_w4m_kernel (four waves, one per SIMD, LDS stage released half a tile early; csrc/gemm_w4.hip) on the three dense
+    layouts of the training step, more than one round of 256 tiles, five K tiles, full and ragged edge tiles: the same bits as the 8-wave
+    kernel (tile code 259: same MFMA, same order of the K sum, same epilogues) and the fp32 product by tolerance; the weight gradient also
+    with fp32 output + accumulate (the generic epilogue)."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(7 + ragged)
+    rn = lambda *s, scale=1.0: (torch.randn(*s, device=DEV, generator=g) * scale).to(BF)
+    M, N, K = (4352 + (40 if ragged else 0)), 4096 + (24 if ragged else 0), 320
+
+    def run(code):
+        with ops.gemm_variant(code):
+            if layout == "fwd":
+                return [ops.linear_fwd(a, b), ops.linear_fwd(a, b, bias=bias, epi="silu", residual=res)]
+            if layout == "dgrad":
+                return [ops.linear_dgrad(a, b)]
+            out = acc0.clone()
+            ops.linear_wgrad(a, b, out=out, accumulate=True)
+            return [ops.linear_wgrad(a, b), out]
+
+    if layout == "fwd":
+        a, b, bias, res = rn(M, K), rn(N, K, scale=K ** -0.5), rn(N), rn(M, N)
+        refs = [a.float() @ b.float().t()]
+        refs.append(F.silu(refs[0] + bias.float()) + res.float())
+    elif layout == "dgrad":                       # dx[M, N] = dy[M, K] W[K, N]
+        a, b = rn(M, K), rn(K, N, scale=K ** -0.5)
+        refs = [a.float() @ b.float()]
+    else:                                         # dW[M, N] = dy[K, M]^T x[K, N] over K tokens
+        a, b = rn(K, M), rn(K, N, scale=K ** -0.5)
+        acc0 = torch.randn(M, N, device=DEV, generator=g)
+        refs = [a.float().t() @ b.float()]
+        refs.append(acc0 + refs[0])
+    got, base = run(280), run(259)
+    for y, y0, ref in zip(got, base, refs):
+        assert rel_l2(y, ref) < (1e-5 if y.dtype == torch.float32 else 4e-3)
+        assert torch.equal(y, y0)
 
 
 @pytest.mark.parametrize("M,Hq,Hkv,K,with_pos", [(256, 2, 2, 64, False), (512, 4, 2, 256, True), (1024, 6, 2, 320, False), (2048, 32, 32, 4096, True)])

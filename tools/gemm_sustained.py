@@ -1,6 +1,6 @@
 """Sustained (power-limited) throughput of the three dominant GEMM layouts per GROUP_M: each point runs ~2.5 s back to back,
 so the number is taken at the clock the socket power limit allows (short bursts run 10-15 % faster).
-python tools/gemm_sustained.py [group_m list, default 2,4,8,16]"""
+python tools/gemm_sustained.py [group_m list, default 2,4,8,16] [seconds per point] [tile code, default 0 = the launcher's choice; 259 / 280]"""
 import os
 import sys
 import time
@@ -13,6 +13,7 @@ from dreamllm_amd import ops  # noqa: E402
 BF = torch.bfloat16
 gms = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "2,4,8,16").split(",")]
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 2.5
+code = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 T = 32768
 # (name, N = out features, K = in features) of the decoder layer's linears (packed q|k|v and gate|up) and one lm_head chunk
 shapes = [("qkv", 12288, 4096), ("o", 4096, 4096), ("gate|up", 22016, 4096), ("down", 4096, 11008)]
@@ -25,7 +26,7 @@ for name, N, K in shapes:
     for kind, fn in fns.items():
         line = f"{name:8s} {kind:6s}"
         for gm in gms:
-            with ops.gemm_variant(0, gm):
+            with ops.gemm_variant(code, gm):
                 fn()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
