@@ -385,7 +385,7 @@ def main():
                 traffic, traffic_detail = None, None
         train = dict(
             value=value, ms_per_step=1e3 * dt / a.steps, loss=loss_val,
-            roofline=dict(bound="mfma", kernel="bf16 MFMA GEMM family: gemm_pipe_kernel / gemm_pipe_tail_kernel / gemm_ring_kernel / gemm_bf16_kernel (linear fwd/dgrad/wgrad + implicit-GEMM conv)",
+            roofline=dict(bound="mfma", kernel="bf16 MFMA GEMM family: gemm_w4m_kernel (the decoder's linears) / gemm_pipe_kernel / gemm_pipe_tail_kernel / gemm_ring_kernel / gemm_bf16_kernel (linear fwd/dgrad/wgrad + implicit-GEMM conv)",
                           achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4),
                           traffic=traffic, traffic_measured=False, traffic_detail=traffic_detail, launches_per_step=len(prof) // max(a.steps, 1),
                           avg_launch_ms=round(1e3 * tsum / max(len(prof), 1), 4),

@@ -59,7 +59,7 @@ static inline int parse_variant(int variant, Variant& v) {
     // 269 / 270: the ring kernel (four- / two-stage) with s_memtime stamps of block 0 / wave 0 around every K tile's wait and barrier,
     // written to the workspace as uint64 (tools/ring_timeline.py): correct results, timing diagnostic only
 #endif
-    if (!ok || (variant >> 28) != 0) return DLLM_ERR_SHAPE;
+    if (!ok || (variant >> 29) != 0) return DLLM_ERR_SHAPE;
     if ((variant >> 27) & 1) v.ring_stages = -1;   // bit 27: the ring kernel always with four stages (round-4 A/B knob)
     v.no_ring = (variant >> 25) & 1;
     v.streamk_ws = (variant >> 26) & 1;
@@ -75,6 +75,7 @@ static inline int parse_variant(int variant, Variant& v) {
     v.force_w4 = tile == 261;
     v.w4m = tile == 280 ? 2 : (tile == 0 ? 1 : 0);
     if (tile == 280) v.glds_pipe = 1;
+    if (((variant >> 28) & 1) && v.w4m == 1) v.w4m = 0;   // bit 28: never choose the four-wave kernel automatically (A/B knob)
     if (v.force_ring) v.force_tile = 0;
     return DLLM_OK;
 }
@@ -1439,7 +1440,9 @@ int dllm_gemm_rope_qkv(const void* x, const void* wqkv, void* qkv, const float* 
     P.epi = EPI_ROPE_QKV; P.alpha = 1.f; P.splitk = 1; P.group_m = (group_m & 0xff) > 0 ? (group_m & 0xff) : 4;
     const int64_t tiles = (M / 256) * (N / 256);
     if (tiles > 0x7fffffff) return DLLM_ERR_SHAPE;
-    if (fused_use_w4m(group_m, tiles, P, A_K, B_K)) return dllm_launch_gemm_w4m(P, A_K, B_K, tiles, (hipStream_t)stream);
+    // (the RoPE epilogue -- table rows gathered per output row -- costs the four-wave kernel more than its K loop gains: 1328 against 1362 TF on the
+    // packed q|k|v projection, profiles/r06_w4m_prefill_fused_ab.log; it runs there only when asked for)
+    if (((group_m >> 8) & 3) == 2 && fused_use_w4m(group_m, tiles, P, A_K, B_K)) return dllm_launch_gemm_w4m(P, A_K, B_K, tiles, (hipStream_t)stream);
     constexpr int LDS = 2 * 2 * 256 * BK * 2;
     static std::atomic<uint64_t> lds_ok{0};
     dllm_ensure_dyn_lds(&gemm_pipe_kernel<A_K, B_K>, LDS, lds_ok);

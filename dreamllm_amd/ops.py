@@ -81,6 +81,11 @@ GEMM_NO_RING |= (1 << 27) if os.environ.get("DREAMLLM_RING_4STAGE", "0") == "1" 
 ATTN_VARIANT = 0
 
 
+# A/B knob (tools / bench): DREAMLLM_W4M=0 keeps the 8-wave 256 x 256 kernel where the library would pick the four-wave one (same results)
+W4M = os.environ.get("DREAMLLM_W4M", "1") != "0"
+NO_W4M_BIT = 1 << 28
+
+
 class gemm_variant:
     def __init__(self, tile=0, group_m=0):
         self.v = int(tile) | (int(group_m) << 16)
@@ -294,12 +299,12 @@ def gemm(a, b, M, N, K, lda, ldb, layout_a, layout_b, *, out=None, out_dtype=tor
             ws = _streamk_workspace(a.device)
             persist = (1 << 24) | STREAMK_WS_BIT
     cnt = _splitk_counters(a.device) if (sk > 1 and SPLITK_FUSED_REDUCE and -(-M // 128) * -(-N // 128) <= 16384) else None
-    variant = GEMM_VARIANT | (persist & STREAMK_WS_BIT)
+    variant = GEMM_VARIANT | (persist & STREAMK_WS_BIT) | (0 if W4M else NO_W4M_BIT)
     if (variant & 0xffff) == 0 and sk == 1 and (variant >> 16) & 0xff == 0:
         gm = _group_m_for(layout_a, layout_b, M, N, K)
         if gm == 0 and GEMM_TUNE_GROUP_M and 2.0 * M * N * K >= _TUNE_MIN_FLOPS:   # opt-in tool, off in the product path
             gm = _tuned_group_m(a, b, out, bias, residual, M, N, K, lda, ldb, ldr, layout_a, layout_b, epi, accumulate, alpha)
-        variant = (gm << 16) | persist
+        variant = (gm << 16) | persist | (0 if W4M else NO_W4M_BIT)
     if (variant & 0xffff) == 0:
         variant |= GEMM_NO_RING if epi != "geglu" else (GEMM_NO_RING & (1 << 27))
     with _GemmTimer((4.0 if epi == "geglu" else 2.0) * M * N * K, _GEMM_TAG[(layout_a, layout_b)]):
@@ -429,7 +434,7 @@ def _ld_too_wide(ld):
 def _glu_group_m(layout, M, N, K):
     """GROUP_M (bits 0-7) and the kernel family (bits 8-9: 0 the library's choice, 1 the 8-wave kernel under `gemm_variant(259)`, 2 the four-wave
     kernel under `gemm_variant(280)`) of the fused entry points."""
-    fam = {259: 1, 280: 2}.get(GEMM_VARIANT & 0xffff, 0)
+    fam = {259: 1, 280: 2}.get(GEMM_VARIANT & 0xffff, 0 if W4M else 1)
     gm = (GEMM_VARIANT >> 16) & 0xff or _group_m_for(layout[0], layout[1], M, N, K)
     return (gm & 0xff) | (fam << 8)
 

@@ -111,7 +111,8 @@ int dllm_gemm_streamk_hint(int64_t M, int64_t N, int64_t K, int layout_a, int la
  * choose the ring-buffered kernel automatically (round 3's selection, an A/B knob); bit 26 = "with splitk <= 1 my workspace is a
  * stream-K workspace of dllm_gemm_streamk_ws_bytes() bytes" -- without it a workspace passed with splitk <= 1 is IGNORED (round 4,
  * round 3 treated any non-NULL workspace as 128 MiB of slab space; a caller re-using its smaller split-K buffer with
- * splitk = 1 would have been written out of bounds); bit 27 = the ring-buffered kernel never takes its two-stage form (A/B knob).
+ * splitk = 1 would have been written out of bounds); bit 27 = the ring-buffered kernel never takes its two-stage form (A/B knob);
+ * bit 28 = never choose the four-wave kernel automatically (round 6's A/B knob: the 8-wave kernel everywhere, as before).
  * 261 = the first (MFMA 32x32x16) form of the four-wave kernel, kept as an experiment.  Tests pass 128 / 256 / 257 / 259 / 262 / 264 / 280 to cover
  * every kernel family.  Anything else returns DLLM_ERR_SHAPE.  (A build with -DDLLM_BENCH_MODES additionally accepts the
  * wrong-result diagnostic modes 258 / 260 / 263 / 265 and the ring kernel's timing diagnostics 269-278 (s_memtime stamps of one block written to

@@ -54,4 +54,26 @@ for name, N, K in shapes:
             tot[c] += min(res[c])
         print(f"{name:8s} {kind:6s} gm{gm}  " + "  ".join(f"[{c}] {min(res[c]):7.3f} ms {flops / min(res[c]) / 1e9:6.0f} TF" for c in codes), flush=True)
     del x, w, dy
+# the fused launches of the decoder layer (family by gemm_variant: 259 / 280 reach the fused entry points through bits 8-9 of group_m)
+from oracle import llm_ref  # noqa: E402  (tools may use the oracle's RoPE tables)
+D = 128
+x = torch.randn(T, 4096, device="cuda").to(BF)
+wqkv = (torch.randn(12288, 4096, device="cuda") * 0.02).to(BF)
+wgu = (torch.randn(22016, 4096, device="cuda") * 0.02).to(BF)
+wd = (torch.randn(4096, 11008, device="cuda") * 0.02).to(BF)
+dy = torch.randn(T, 4096, device="cuda").to(BF)
+gu = torch.randn(T, 22016, device="cuda").to(BF)
+cos, sin = llm_ref.rope_tables(D, 2048)
+ct, st = cos[:, : D // 2].contiguous().cuda(), sin[:, : D // 2].contiguous().cuda()
+fused = {"qkv + RoPE fwd": (lambda: ops.linear_rope_qkv(x, wqkv, ct, st, None, 64, D, 2048), 2.0 * T * 12288 * 4096),
+         "gate|up + SwiGLU fwd": (lambda: ops.linear_swiglu_fwd(x, wgu), 2.0 * T * 22016 * 4096),
+         "down dgrad + SwiGLU bwd": (lambda: ops.linear_dgrad_swiglu(dy, wd, gu), 2.0 * T * 11008 * 4096)}
+for name, (fn, flops) in fused.items():
+    res = {c: [] for c in codes}
+    for _ in range(2):
+        for c in codes:
+            with ops.gemm_variant(c):
+                assert fn() is not None
+                res[c].append(sustained(fn))
+    print(f"{name:24s}  " + "  ".join(f"[{c}] {min(res[c]):7.3f} ms {flops / min(res[c]) / 1e9:6.0f} TF" for c in codes), flush=True)
 print("sum of the twelve  " + "  ".join(f"[{c}] {tot[c]:8.3f} ms" for c in codes))
