@@ -1,26 +1,32 @@
-// Round 6 (VERDICT r05 "next" #1: the hand-scheduled K loop): a FOUR-wave form of the 256 x 256 x 64 bf16 GEMM -- one wave per SIMD,
-// wave tile 128 x 128 on v_mfma_f32_32x32x16_bf16 (sixteen 32 x 32 accumulators = 256 registers of the 512 a lone wave owns), operands by
-// LDS-DMA in the buffer form.  Rounds 1-2 measured this geometry 10-25 % SLOWER than the 8-wave kernel and explained it by the ~125
-// cycles an LDS-DMA request cost the issuing wave, with nobody to cover for a lone wave.  tools/dma_issue_probe.hip (this round) shows
-// that figure belonged to the addressing form: at one wave per SIMD a global_load_lds_dwordx4 with 64-bit per-lane addresses costs ~100
-// clk beside 8 MFMAs, buffer_load_dwordx4 ... offen lds ~16.  So the experiment is repeated with what changed:
-//   * every instruction that is not an MFMA is a FILLER behind an MFMA: per 64-deep K tile a wave issues 64 MFMAs (32 clk each = the whole
-//     K tile's 2048 matrix cycles of its SIMD), 32 ds_read_b128 (the 8 fragments of the next 16-deep k step behind the first 8 MFMAs of every
-//     step) and 16 DMA requests (behind the last 8 MFMAs of k steps 3 and 0) -- at most one filler per MFMA gap;
-//   * a k step's fragments are requested a whole half step (>= 256 clk) before their wait, the tile barrier sits at the start of the LAST k
-//     step of a tile (its fragments are in registers by then), so the first reads of the next tile run under 16 MFMAs;
-//   * LDS traffic per K tile: 4 waves x 32 reads = 128 KiB (8-wave kernel: 192 KiB), half the waves at the barrier.
-// Forward layout (both operands k-contiguous), full 256-tiles, plain bf16 epilogue: enough to measure the K loop against
-// gemm_pipe_kernel (tile code 261 beside 259 in tools/gemm_bench.py); the result decides whether the other layouts follow.
+// Round 6 (VERDICT r05 "next" #1: the hand-scheduled K loop): FOUR-wave forms of the 256 x 256 x 64 bf16 GEMM -- one wave per SIMD, wave tile
+// 128 x 128, 256 accumulator registers in AGPRs, operands by LDS-DMA in the buffer form, two LDS stages.
 //
-// RESULT (profiles/r06_gemm_w4_bench.log, r06_pmc_gemm_w4.txt, r06_gemm_w4_clock.log).  hipcc emits exactly the intended
-// stream (ISA checked: 64 MFMAs on 256 AGPR accumulators per K tile, one ds_read_b128 or one `s_add m0` + buffer_load ... lds behind each,
-// no v_accvgpr moves, 94 VGPRs, no spills), and the wave parks for 14 % of its cycles instead of 32 % (SQ_WAIT_ANY), matrix pipe busy 76 %
-// of the GPU cycles against 74 %.  It is nevertheless 2-4 % SLOWER (1257-1300 TF against 1290-1330 on the forward shapes): both kernels sit on
-// the 1.4 kW socket power limit, and the denser stream is answered with a lower clock -- 1.76 GHz sustained against 1.91 GHz for the 8-wave
-// kernel (tools/clock_probe.py gemm261 / gemm259).  The GEMM is power-bound, not schedule-bound: at this limit a tighter K loop buys clock
-// back only through fewer joules per FLOP, and MFMA 32x32x16 moves twice the accumulator registers per FLOP of 16x16x32.  Not the default;
-// kept reachable (tile code 261) with its test as the documented end point of the "hand-scheduled K loop" line of work.
+//   gemm_w4m_kernel<AL, BL, EK>  (MFMA 16x16x32; tile code 280; the launcher's choice for the decoder's linears)   -- the product kernel
+//   gemm_w4_kernel               (MFMA 32x32x16; tile code 261; forward layout, plain epilogue)                  -- the experiment it grew from
+//
+// What the round measured, in order (profiles/r06_power_probe*.log, r06_w4*_diag.log, r06_gemm_w4m_sustained.log):
+//  1. The first four-wave kernel (one filler per MFMA, tile barrier in the last k step) ran its matrix pipe 76 % busy and was still 2-4 % slower
+//     than the 8-wave kernel; both sat on the 1.4 kW socket limit, and the round first read that as "power-bound, not schedule-bound".
+//  2. tools/power_probe.py ended that reading: on ZERO operands (no power limit, 2.4 GHz) the 8-wave kernel does 1.45 PF, that four-wave kernel
+//     1.51 PF, hipBLASLt's hand-written kernel for the shape 2.15 PF.  Both of ours were bound by something that does not scale with the clock:
+//     the turn-around of an LDS stage.  With two stages a tile's requests can only go out once EVERY wave has read the stage they land in, and
+//     have to be back one tile later: less than a K tile (0.85 us) for L2 misses that take longer under load.
+//  3. hipBLASLt's kernel (disassembled from its code object: same tile, same MFMA count, same two stages) reads a tile's fragments into
+//     registers EARLY -- the second k step's while the first one's MFMAs run -- and releases the stage half a tile before its MFMAs end; its
+//     requests then have 1.0-1.45 K tiles to land.  That is the pipeline below: by g = 32 of 128 a wave holds the whole tile in 128 fragment
+//     registers, the A half of the stage is released at g = 32, the B half at g = 48, the data of tile t + 1 is awaited at g = 96.
+//  4. With all 16 requests of a wave inside 512 clk the four waves queue behind one another on the vector L1 (64 B/clk = one 1-KiB request per
+//     16 clk for the CU; an all-L2-hit diagnostic still lost 20 %): one request per six MFMAs (96 clk) per wave.  Zero operands: 1.51 -> 1.69
+//     (early release) -> 1.92 PF (spread requests) on MFMA 32x32x16.
+//  5. Under the power limit the 32x32x16 form gave most of it back (1.36 PF at 1.69 GHz); the same pipeline on MFMA 16x16x32 draws 12 % less
+//     per FLOP: 1.47 PF at 1.81-1.88 GHz on the packed gate|up forward against 1.33 (8-wave) and 1.54-1.59 (hipBLASLt) on the same box.
+//  6. hipcc details that cost a day's worth of confusion: (a) the MFMAs are inline asm with "+a" accumulators (the builtin spread the 64
+//     accumulators over both register files: ~500 v_accvgpr moves per K tile); hipcc then does not know they are MFMAs and read an accumulator
+//     one s_nop behind its last MFMA -- empty "+a" statements behind the closing barrier order the epilogue; (b) with every epilogue inlined the
+//     K loop ran out of SGPRs, the request descriptors were spilled to VGPRs and every request became a readfirstlane waterfall loop (-11 %):
+//     the epilogue family is a template parameter and the generic gemm_epilogue is not instantiated here (the launcher sends full bf16 tiles only).
+// Result on the twelve big linears of the step, sustained, against the 8-wave kernel: +2 ... +11 % each, 29.4 -> 27.2 ms in sum; the training
+// step 12.06-12.25 -> 12.81 samples/s, GEMM family 0.496-0.506 -> 0.532 of the bf16 peak.  Same bits as the 8-wave kernel (tests).
 #include "gemm_shared.h"
 #include "gemm_epilogues.h"
 
