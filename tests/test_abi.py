@@ -122,3 +122,27 @@ def test_scheduling_hints_are_pure_host_functions():
     # weight-gradient layouts of a small grid run on the register-staged kernel and take its (many-slices) rule
     assert h(512, 1280, 11520, 2, 0) == 6 and h(512, 1280, 11520, 0, 1) == 10 and h(512, 1280, 11520, 1, 1) == 10
     assert _lib.call("dllm_gemm_streamk_ws_bytes") == (2 * 256 * 256 * 256 + 1024) * 4
+
+
+def test_gemm_kernel_family_knobs_are_plain_arguments():
+    """Round 6: the four-wave GEMM kernel is chosen per call -- `variant` tile code 280 / bit 28 of `variant`, bits 8-9 of the fused entry
+    points' `group_m` -- and the Python side derives those bits from `gemm_variant` / DREAMLLM_W4M alone (no library state).  Host logic only."""
+    from dreamllm_amd import ops
+    key = (0, 0, 32768, 22016, 4096)
+    gm = ops._group_m_for(*key)
+    assert gm == 8
+    prev = ops.W4M
+    try:
+        ops.W4M = True
+        assert ops._glu_group_m((0, 0), *key[2:]) == gm                      # family 0: the library's choice
+        with ops.gemm_variant(259):
+            assert ops._glu_group_m((0, 0), *key[2:]) == (gm | (1 << 8))     # the 8-wave kernel
+        with ops.gemm_variant(280, 3):
+            assert ops._glu_group_m((0, 0), *key[2:]) == (3 | (2 << 8))      # the four-wave kernel, GROUP_M from the variant
+        ops.W4M = False
+        assert ops._glu_group_m((0, 0), *key[2:]) == (gm | (1 << 8))         # DREAMLLM_W4M=0: the 8-wave kernel everywhere
+        assert ops.NO_W4M_BIT == 1 << 28
+    finally:
+        ops.W4M = prev
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dreamllm_hip.h")).read()
+    assert "280 the four-wave kernel" in hdr and "bit 28 = never choose the four-wave kernel" in hdr and "bits 8-9 the kernel family" in hdr
