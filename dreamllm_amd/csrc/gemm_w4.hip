@@ -259,7 +259,23 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmParams P) {
 // order -- so its epilogues apply per half and the results are bit-identical to the 8-wave kernel's.
 constexpr int w4m_i(int g) { return g < 32 ? ((g & 15) >> 2) : 4 + ((g - 32) >> 3); }   // MFMA order inside a k step: A 0-3 x B 0-3, A 0-3 x B 4-7
 constexpr int w4m_j(int g) { return g < 16 ? (g & 3) : (g < 32 ? 4 + (g & 3) : ((g - 32) & 7)); }   // (the order the fragments are read in), rows 4-7
-constexpr int w4m_cap(int n) { return n > 15 ? 15 : n; }   // lgkmcnt is a 4-bit counter; waiting for one operation more is always safe
+constexpr int w4m_cap(int n) { return n > 15 ? 15 : n; }
+// schedule points of a K tile (MFMA index g of 128): release of the A / B half of the stage, first request, request spacing
+#ifndef W4M_RA
+#define W4M_RA 32
+#endif
+#ifndef W4M_RB
+#define W4M_RB 48
+#endif
+#ifndef W4M_Q0
+#define W4M_Q0 32
+#endif
+#ifndef W4M_QS
+#define W4M_QS 6
+#endif
+constexpr int w4m_req_at(int g) { return (g >= W4M_Q0 && (g - W4M_Q0) % W4M_QS == 0 && (g - W4M_Q0) / W4M_QS < 16) ? (g - W4M_Q0) / W4M_QS : -1; }
+constexpr int w4m_reqs_before(int g) { int n = 0; for (int r = 0; r < 16; ++r) n += (W4M_Q0 + W4M_QS * r < g) ? 1 : 0; return n; }
+static_assert(W4M_RA >= 24 && (W4M_RA % 2) == 0 && W4M_RB >= 40 && W4M_RB >= W4M_RA + 8 && W4M_Q0 >= W4M_RA && W4M_Q0 + 8 * W4M_QS >= W4M_RB && W4M_Q0 + 15 * W4M_QS < 128, "requests behind the releases");   // lgkmcnt is a 4-bit counter; waiting for one operation more is always safe
 
 // (a function, not a statement inside a generic lambda: inline-asm operands there do not count as captures)
 __device__ __forceinline__ void w4m_tie(f32x4 (&a)[8][4]) {
@@ -422,19 +438,19 @@ __global__ __launch_bounds__(256, 1) void gemm_w4m_kernel(GemmParams P) {
             constexpr int g = decltype(gc)::value, ks = g >> 6, n = g & 63, i = w4m_i(n), j = w4m_j(n);
             if constexpr (g == 0) wait_set(std::integral_constant<int, 4 * OA + 4 * OB>{}, std::integral_constant<int, 0>{});   // A 0-3, B 0-3 of k step 0 are in
             if constexpr (g == 16) wait_set(std::integral_constant<int, 8 * OA>{}, std::integral_constant<int, 0>{});           // all of k step 0
-            if constexpr (g == 32) {
-                wait_set(std::integral_constant<int, 8 * OB>{}, std::integral_constant<int, 1>{});   // the A reads of k step 1 are in; its B reads may be out
+            if constexpr (g == W4M_RA) {
+                wait_set(std::integral_constant<int, (W4M_RA >= 32 ? 8 : (W4M_RA - 16) / 2) * OB>{}, std::integral_constant<int, 1>{});   // the A reads of k step 1 are in; its B reads may be out
                 if constexpr (HAS2) {
                     __builtin_amdgcn_s_barrier();
                     advance();
                 }
             }
-            if constexpr (g == 48) {
+            if constexpr (g == W4M_RB) {
                 wait_set(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
                 if constexpr (HAS2) __builtin_amdgcn_s_barrier();
             }
             if constexpr (g == 96 && HAS1) {
-                if constexpr (HAS2) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+                if constexpr (HAS2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(w4m_reqs_before(96)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -442,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4m_kernel(GemmParams P) {
             // files and shuffles ~500 v_accvgpr moves per K tile between them)
             asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j >> 2][i][j & 3]) : "v"(fragr_value(fb[ks][j])), "v"(fragr_value(fa[ks][i])));
             if constexpr (g < 32 && (g & 1) == 0) read1(std::integral_constant<int, g / 2>{}, ab, bb);
-            if constexpr (HAS2 && g >= 32 && (g - 32) % 6 == 0 && (g - 32) / 6 < 16) request(cb, (g - 32) / 6);
+            if constexpr (HAS2 && w4m_req_at(g) >= 0) request(cb, w4m_req_at(g));
             if constexpr (HAS1 && g >= 96 && (g & 1) == 0) read0(std::integral_constant<int, (g - 96) / 2>{}, abn, bbn);
             __builtin_amdgcn_sched_barrier(0);
         });
