@@ -175,6 +175,40 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
     }
 }
 
+// Round 6: the same pass with the channel vector FIXED per thread: thread (p, cv) of a 512-thread block owns 16-byte vector cv of pixels
+// p, p + PPB, ... of one image (blockIdx.y), so its 8 (a, b) pairs live in registers and the loop body is load - 8 fma (+ SiLU) - store: no
+// 64-bit division / modulo per vector, no coefficient loads per element (the grid-stride form above spends ~60 integer and address instructions
+// per vector and streams at 3.5 TB/s; the training step's VAE tensors are 2 GB each).  C <= 4096.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void gn_apply_cv_kernel(const bf16* __restrict__ x, const float* __restrict__ ab, bf16* __restrict__ y,
+                                                            int HW, int C, int act) {
+    const int CV = C >> 3, PPB = BLOCK / CV;
+    const int tid = threadIdx.x;
+    if (tid >= PPB * CV) return;
+    const int p0 = tid / CV, cv = tid - p0 * CV;
+    const int64_t n = blockIdx.y;
+    float a[8], b[8];
+    const float* pc = ab + (n * C + cv * 8) * 2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        a[e] = pc[e * 2];
+        b[e] = pc[e * 2 + 1];
+    }
+    const bf16* xi = x + n * HW * (int64_t)C + cv * 8;
+    bf16* yi = y + n * HW * (int64_t)C + cv * 8;
+    for (int pix = blockIdx.x * PPB + p0; pix < HW; pix += gridDim.x * PPB) {
+        const bf16x8 v = ld_bf16x8(xi + (int64_t)pix * C);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float z = (float)v[e] * a[e] + b[e];
+            if (act) z = silu_f(z);
+            o[e] = (bf16)z;
+        }
+        st_bf16x8(yi + (int64_t)pix * C, o);
+    }
+}
+
 // Small problems (the UNet at batch 2 inside the denoise loop: 0.3 - 16 MB per tensor, L2 / MALL resident): ONE launch, one block
 // per (image, group).  Thread (r, j) owns channel pair j of the group and pixels r, r + R, ...: 4-byte loads (a group is C/G
 // channels = 20 - 160 contiguous bytes per pixel), no division in the loops; pass 1 sum / sum of squares, block reduce, pass 2
@@ -422,6 +456,51 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16* __restric
     }
 }
 
+// the same with the channel vector fixed per thread (see gn_apply_cv_kernel): the per-channel statistics, c1 / c2 and the affine parameters of
+// the thread's 8 channels are read ONCE; the grid-stride form above pays 8 integer divisions and 6 scalar-table loads per vector
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void gn_bwd_apply_cv_kernel(const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                const float* __restrict__ c1, const float* __restrict__ c2,
+                                                                const bf16* __restrict__ gamma, const bf16* __restrict__ beta,
+                                                                bf16* __restrict__ dx, int HW, int C, int G, int act) {
+    const int CV = C >> 3, PPB = BLOCK / CV, cpg = C / G;
+    const int tid = threadIdx.x;
+    if (tid >= PPB * CV) return;
+    const int p0 = tid / CV, cv = tid - p0 * CV;
+    const int n = blockIdx.y;
+    float rs[8], mu[8], k1[8], k2[8], ga[8], be[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = cv * 8 + e;
+        const int ng = n * G + c / cpg;
+        rs[e] = rstd[ng];
+        mu[e] = mean[ng];
+        k1[e] = c1[ng];
+        k2[e] = c2[ng];
+        ga[e] = (float)gamma[c];
+        be[e] = (float)beta[c];
+    }
+    const int64_t base = (int64_t)n * HW * C + cv * 8;
+    for (int pix = blockIdx.x * PPB + p0; pix < HW; pix += gridDim.x * PPB) {
+        const int64_t off = base + (int64_t)pix * C;
+        const bf16x8 v = ld_bf16x8(x + off), d = ld_bf16x8(dy + off);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xh = ((float)v[e] - mu[e]) * rs[e];
+            float dz = (float)d[e];
+            if (act) {
+                const float z = xh * ga[e] + be[e];
+                const float sg = sigmoid_f(z);
+                dz *= sg * (1.f + z * (1.f - sg));
+            }
+            o[e] = (bf16)(rs[e] * (dz * ga[e] - k1[e] - xh * k2[e]));
+        }
+        st_bf16x8(dx + off, o);
+    }
+}
+
 // 2x2 sum pooling on NHWC: backward of nearest-2x upsampling.  in [N,2H,2W,C] -> out [N,H,W,C]
 __global__ __launch_bounds__(256) void sumpool2_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, int64_t total_vec,
                                                        int H, int W, int C) {
@@ -466,6 +545,16 @@ inline int gn_geometry(int HW, int C, int NB, int* block, int* nchunks, int* ppc
 
 }  // namespace
 
+// grid of the *_cv_kernel<512> apply passes: x = pixel chunks (about 4096 blocks in all: ~16 per CU), y = image
+static inline dim3 gn_cv_grid(int NB, int HW, int C) {
+    const int ppb = 512 / (C >> 3);
+    const int need = (HW + ppb - 1) / ppb;
+    int gx = 4096 / (NB > 0 ? NB : 1);
+    if (gx < 1) gx = 1;
+    if (gx > need) gx = need;
+    return dim3((unsigned)gx, (unsigned)NB);
+}
+
 extern "C" {
 
 // workspace sizes (floats): partials = N * nchunks * C * 2
@@ -496,6 +585,11 @@ int dllm_groupnorm_fwd(const void* x, const void* gamma, const void* beta, void*
                        nullptr, nullptr, part, HW, C, G, ppc, 0);
     hipLaunchKernelGGL(gn_finalize_kernel<0>, dim3(NB * G), dim3(64), 0, s, part, (const bf16*)gamma, (const bf16*)beta, mean,
                        rstd, ab, nchunks, HW, C, G, eps, (const bf16*)x);
+    if ((C & 7) == 0 && C <= 4096 && NB <= 65535) {   // channel vector fixed per thread (round 6)
+        const dim3 g = gn_cv_grid(NB, HW, C);
+        hipLaunchKernelGGL(gn_apply_cv_kernel<512>, g, dim3(512), 0, s, (const bf16*)x, ab, (bf16*)y, HW, C, act);
+        return dllm_check_launch();
+    }
     const int64_t tv = (int64_t)NB * HW * (C / 8);
     int grid = (int)((tv + 255) / 256 > 8192 ? 8192 : (tv + 255) / 256);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, ab, (bf16*)y, tv, HW, C, act);
@@ -532,6 +626,12 @@ int dllm_groupnorm_bwd(const void* dy, const void* x, const void* gamma, const v
                        (const bf16*)gamma, (const bf16*)beta, part, HW, C, G, ppc, act);
     hipLaunchKernelGGL(gn_finalize_kernel<1>, dim3(NB * G), dim3(64), 0, s, part, nullptr, nullptr, c1, c2, nullptr, nchunks, HW,
                        C, G, 0.f, (const bf16*)nullptr);
+    if ((C & 7) == 0 && C <= 4096 && NB <= 65535) {
+        const dim3 g = gn_cv_grid(NB, HW, C);
+        hipLaunchKernelGGL(gn_bwd_apply_cv_kernel<512>, g, dim3(512), 0, s, (const bf16*)x, (const bf16*)dy, mean, rstd, c1, c2, (const bf16*)gamma,
+                           (const bf16*)beta, (bf16*)dx, HW, C, G, act);
+        return dllm_check_launch();
+    }
     const int64_t tv = (int64_t)NB * HW * (C / 8);
     int grid = (int)((tv + 255) / 256 > 8192 ? 8192 : (tv + 255) / 256);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, mean, rstd, c1, c2,
