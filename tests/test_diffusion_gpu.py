@@ -119,7 +119,10 @@ def test_conv_epilogue_image_bias_and_residual():
 
 @pytest.mark.parametrize("N,HW,C,act", [(2, 64, 320, True), (3, 256, 64, False), (1, 1024, 1280, True), (2, 100, 960, True),
                                         (2, 4096, 128, True),
-                                        (4, 4096, 640, True)])   # > 2^23 elements: the three-launch path (smaller: one launch)
+                                        (4, 4096, 640, True),    # > 2^23 elements: the three-launch path (smaller: one launch)
+                                        (2, 4096, 2560, True),   # round 6 apply kernels: 320 channel vectors = one pixel per 512-thread pass
+                                        (3, 4099, 960, False),   # ... odd pixel count against 4 pixels per pass
+                                        (1, 2048, 4608, True)])  # ... more than 4096 channels: the grid-stride apply kernels
 def test_groupnorm_fwd_bwd(N, HW, C, act):
     ops = _ops()
     torch.manual_seed(C + HW)
