@@ -53,6 +53,7 @@ SIGNATURES = {
     "dllm_gather_rows": [c_void_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_void_p],
     "dllm_scatter_rows": [c_void_p] * 3 + [c_i64, c_int, c_i64, c_i64, c_void_p],
     "dllm_segment_sum_rows": [c_void_p] * 5 + [c_i64, c_int, c_i64, c_i64, c_void_p],
+    "dllm_segment_sum_rows_ex": [c_void_p] * 5 + [c_i64, c_int, c_i64, c_i64, c_int, c_int, c_void_p],
     "dllm_cross_entropy": [c_void_p] * 5 + [c_i64, c_int, c_i64, c_i64, c_void_p],
     "dllm_softmax_rows": [c_void_p, c_void_p, c_i64, c_int, c_i64, c_i64, c_void_p],
     "dllm_adamw": [c_void_p] * 4 + [c_i64, c_int, c_int] + [c_float] * 5 + [c_int, c_float, c_void_p, c_void_p],

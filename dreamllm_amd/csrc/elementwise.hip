@@ -135,40 +135,67 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16* __restric
     }
 }
 // Embedding backward, deterministic: rows sorted by token id; seg_start[u]..seg_start[u+1] are the positions (into
-// `order`) of unique id uid[u].  dtable[uid[u],:] = sum_{j in segment} dy[order[j],:]  (fp32 accumulation).
-__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const bf16* __restrict__ dy, const int64_t* __restrict__ order,
+// `order`; order == null: the rows themselves) of unique id uid[u].  dtable[uid[u],:] = sum_{j in segment} dy[order[j],:]  (fp32 accumulation).
+// FIN / FOUT: fp32 rows in / out (round 6: a segment of ~10^4 positions -- one block, ~25 GB/s -- took 2.7 ms of every training step; the
+// caller now cuts long segments into chunks, sums the chunks into fp32 partial rows here and the partial rows of a token in a second
+// call: dllm_segment_sum_rows_ex).
+template <bool FIN>
+__device__ __forceinline__ void seg_load8(const void* base, int64_t row, int64_t ld, int v, float (&d)[8]) {
+    if constexpr (FIN) {
+        const float* p = reinterpret_cast<const float*>(base) + row * ld + v * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            d[e] = a[e];
+            d[e + 4] = b[e];
+        }
+    } else {
+        const bf16x8 t = ld_bf16x8(reinterpret_cast<const bf16*>(base) + row * ld + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = (float)t[e];
+    }
+}
+template <bool FIN, bool FOUT>
+__global__ __launch_bounds__(256) void segment_sum_rows_kernel(const void* __restrict__ dy, const int64_t* __restrict__ order,
                                                                const int64_t* __restrict__ seg_start,
-                                                               const int64_t* __restrict__ uid, bf16* __restrict__ dtable,
+                                                               const int64_t* __restrict__ uid, void* __restrict__ dtable,
                                                                int64_t nuniq, int D, int64_t ld_dy, int64_t ld_t) {
     const int vpr = D >> 3;
     for (int64_t u = blockIdx.x; u < nuniq; u += gridDim.x) {
         const int64_t s0 = seg_start[u], s1 = seg_start[u + 1];
+        const int64_t orow = uid ? uid[u] : u;
         for (int v = threadIdx.x; v < vpr; v += 256) {
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             int64_t j = s0;
-            // long segments (the <im_patch> id covers ~10^4 positions of a batch) are walked 8 rows at a time: 8 independent
-            // index loads, then 8 independent row loads in flight, summed in the original order (deterministic)
+            // 8 rows at a time: 8 independent index loads, then 8 independent row loads in flight, summed in the original order (deterministic)
             for (; j + 8 <= s1; j += 8) {
                 int64_t idx[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) idx[q] = order[j + q];
-                bf16x8 d[8];
+                for (int q = 0; q < 8; ++q) idx[q] = order ? order[j + q] : j + q;
+                float d[8][8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) d[q] = ld_bf16x8(dy + idx[q] * ld_dy + v * 8);
+                for (int q = 0; q < 8; ++q) seg_load8<FIN>(dy, idx[q], ld_dy, v, d[q]);
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += (float)d[q][e];
+                    for (int e = 0; e < 8; ++e) acc[e] += d[q][e];
             }
             for (; j < s1; ++j) {
-                const bf16x8 d = ld_bf16x8(dy + order[j] * ld_dy + v * 8);
+                float d[8];
+                seg_load8<FIN>(dy, order ? order[j] : j, ld_dy, v, d);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += (float)d[e];
+                for (int e = 0; e < 8; ++e) acc[e] += d[e];
             }
-            bf16x8 o;
+            if constexpr (FOUT) {
+                float* p = reinterpret_cast<float*>(dtable) + orow * ld_t + v * 8;
+                *reinterpret_cast<f32x4*>(p) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+                *reinterpret_cast<f32x4*>(p + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+            } else {
+                bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
-            st_bf16x8(dtable + uid[u] * ld_t + v * 8, o);
+                for (int e = 0; e < 8; ++e) o[e] = (bf16)acc[e];
+                st_bf16x8(reinterpret_cast<bf16*>(dtable) + orow * ld_t + v * 8, o);
+            }
         }
     }
 }
@@ -684,14 +711,24 @@ int dllm_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n,
                        idx, (bf16*)dst, n, D, ld_s, ld_d);
     return dllm_check_launch();
 }
-int dllm_segment_sum_rows(const void* dy, const int64_t* order, const int64_t* seg_start, const int64_t* uid, void* dtable,
-                          int64_t nuniq, int D, int64_t ld_dy, int64_t ld_t, void* stream) {
-    if (nuniq < 0 || D <= 0 || (D & 7) || ((ld_dy | ld_t) & 7)) return DLLM_ERR_SHAPE;
+int dllm_segment_sum_rows_ex(const void* dy, const int64_t* order, const int64_t* seg_start, const int64_t* uid, void* dtable,
+                             int64_t nuniq, int D, int64_t ld_dy, int64_t ld_t, int in_dtype, int out_dtype, void* stream) {
+    if (nuniq < 0 || D <= 0 || (D & 7) || ((ld_dy | ld_t) & 7) || seg_start == nullptr) return DLLM_ERR_SHAPE;
+    if ((in_dtype != DLLM_BF16 && in_dtype != DLLM_F32) || (out_dtype != DLLM_BF16 && out_dtype != DLLM_F32)) return DLLM_ERR_SHAPE;
     if (nuniq == 0) return DLLM_OK;
     const int g = (int)(nuniq < 4096 ? nuniq : 4096);
-    hipLaunchKernelGGL(segment_sum_rows_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, order, seg_start,
-                       uid, (bf16*)dtable, nuniq, D, ld_dy, ld_t);
+    hipStream_t s = (hipStream_t)stream;
+    const bool fi = in_dtype == DLLM_F32, fo = out_dtype == DLLM_F32;
+    if (!fi && !fo) hipLaunchKernelGGL((segment_sum_rows_kernel<false, false>), dim3(g), dim3(256), 0, s, dy, order, seg_start, uid, dtable, nuniq, D, ld_dy, ld_t);
+    else if (!fi && fo) hipLaunchKernelGGL((segment_sum_rows_kernel<false, true>), dim3(g), dim3(256), 0, s, dy, order, seg_start, uid, dtable, nuniq, D, ld_dy, ld_t);
+    else if (fi && !fo) hipLaunchKernelGGL((segment_sum_rows_kernel<true, false>), dim3(g), dim3(256), 0, s, dy, order, seg_start, uid, dtable, nuniq, D, ld_dy, ld_t);
+    else hipLaunchKernelGGL((segment_sum_rows_kernel<true, true>), dim3(g), dim3(256), 0, s, dy, order, seg_start, uid, dtable, nuniq, D, ld_dy, ld_t);
     return dllm_check_launch();
+}
+int dllm_segment_sum_rows(const void* dy, const int64_t* order, const int64_t* seg_start, const int64_t* uid, void* dtable,
+                          int64_t nuniq, int D, int64_t ld_dy, int64_t ld_t, void* stream) {
+    if (order == nullptr || uid == nullptr) return DLLM_ERR_SHAPE;
+    return dllm_segment_sum_rows_ex(dy, order, seg_start, uid, dtable, nuniq, D, ld_dy, ld_t, DLLM_BF16, DLLM_BF16, stream);
 }
 
 // softmax over the last dimension: x fp32 [rows][cols] (row pitch ld_x, multiple of 4) -> y bf16 (row pitch ld_y, multiple of 4)

@@ -663,6 +663,10 @@ def scatter_rows_(dst, idx, src):
     return dst
 
 
+# positions per chunk of the embedding gradient's segment sums (0: one work-group per token id, as before round 6)
+EMB_BWD_CHUNK = int(os.environ.get("DREAMLLM_EMB_BWD_CHUNK", "128"))
+
+
 def embedding_bwd(dy, ids, num_rows):
     """Deterministic embedding gradient: sort ids, segment-sum rows in fp32."""
     dy2 = dy.reshape(-1, dy.shape[-1])
@@ -674,8 +678,30 @@ def embedding_bwd(dy, ids, num_rows):
     seg = torch.zeros(uid.numel() + 1, dtype=torch.int64, device=ids.device)
     seg[1:] = torch.cumsum(counts, 0)
     dtable = torch.zeros(num_rows, dy2.shape[1], dtype=dy.dtype, device=dy.device)
-    check("dllm_segment_sum_rows", _p(dy2), _p(order.contiguous()), _p(seg), _p(uid.contiguous()), _p(dtable), uid.numel(),
-          dy2.shape[1], dy2.stride(0), dtable.stride(0), _stream())
+    U, D = uid.numel(), dy2.shape[1]
+    order = order.contiguous()
+    if EMB_BWD_CHUNK > 0 and dy.dtype == torch.bfloat16 and ids.numel() >= 16 * EMB_BWD_CHUNK:
+        # one work-group walks a segment: a token with ~10^4 positions in the batch (the image placeholder) took 2.7 ms alone.  Segments are
+        # cut into chunks of EMB_BWD_CHUNK positions, the chunks summed into fp32 partial rows, then each token's partial rows in order
+        # (deterministic; tokens with a single chunk -- all but a handful -- add their rows in the same order as before)
+        L = EMB_BWD_CHUNK
+        nchunk = (counts + (L - 1)) // L
+        vfirst = torch.zeros(U + 1, dtype=torch.int64, device=ids.device)
+        vfirst[1:] = torch.cumsum(nchunk, 0)
+        V = int(vfirst[-1])   # (the sort / unique above already synchronised with the host)
+        if V > U:
+            u_of_v = torch.repeat_interleave(torch.arange(U, device=ids.device), nchunk, output_size=V)
+            c_of_v = torch.arange(V, device=ids.device) - vfirst[u_of_v]
+            vseg = torch.empty(V + 1, dtype=torch.int64, device=ids.device)
+            vseg[:V] = seg[u_of_v] + c_of_v * L
+            vseg[V] = ids.numel()
+            partial = torch.empty(V, D, dtype=torch.float32, device=dy.device)
+            check("dllm_segment_sum_rows_ex", _p(dy2), _p(order), _p(vseg), None, _p(partial), V, D, dy2.stride(0), D, 0, 1, _stream())
+            check("dllm_segment_sum_rows_ex", _p(partial), None, _p(vfirst), _p(uid.contiguous()), _p(dtable), U, D, D, dtable.stride(0), 1, 0,
+                  _stream())
+            return dtable
+    check("dllm_segment_sum_rows", _p(dy2), _p(order), _p(seg), _p(uid.contiguous()), _p(dtable), U, D, dy2.stride(0),
+          dtable.stride(0), _stream())
     return dtable
 
 

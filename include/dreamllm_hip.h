@@ -209,9 +209,15 @@ int dllm_gather_rows(const void* table, const int64_t* idx, void* out, int64_t n
 /* the multimodal splice (dream queries :1081-1099, image features :1104-1141) as one index scatter: dst[idx[i]] = src[i] */
 int dllm_scatter_rows(const void* src, const int64_t* idx, void* dst, int64_t n, int D, int64_t ld_s, int64_t ld_d,
                       void* stream);
-/* deterministic nn.Embedding backward over id-sorted rows */
+/* deterministic nn.Embedding backward over id-sorted rows (modeling_dreamllm.py:1066: the gradient of embed_tokens):
+ * dtable[uid[u], :] = sum over j in [seg_start[u], seg_start[u+1]) of dy[order[j], :], fp32 accumulation in the order of j. */
 int dllm_segment_sum_rows(const void* dy, const int64_t* order, const int64_t* seg_start, const int64_t* uid, void* dtable,
                           int64_t nuniq, int D, int64_t ld_dy, int64_t ld_t, void* stream);
+/* the same with fp32 rows in and / or out (in_dtype / out_dtype: DLLM_BF16 | DLLM_F32), order == NULL (segments of consecutive rows) and
+ * uid == NULL (segment u -> row u): a token with ~10^4 positions in a batch (one work-group walking them: 2.7 ms) is summed in two calls --
+ * chunks of its segment into fp32 partial rows, then the partial rows of each token into the table. */
+int dllm_segment_sum_rows_ex(const void* dy, const int64_t* order, const int64_t* seg_start, const int64_t* uid, void* dtable,
+                             int64_t nuniq, int D, int64_t ld_dy, int64_t ld_t, int in_dtype, int out_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------- losses
  * logits.float() + CrossEntropyLoss(reduction="none") + masked mean, modeling_dreamllm.py:1453-1470: per-row loss and

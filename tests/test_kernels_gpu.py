@@ -579,6 +579,34 @@ def test_gather_scatter_embedding_bwd():
     assert rel_l2(dt, ref) < 4e-3
 
 
+def test_embedding_bwd_long_segments_take_the_chunked_path():
+    """A batch where one id (the image placeholder) covers a third of the positions and a few others hundreds: the chunked two-call form
+    (fp32 partial rows per ops.EMB_BWD_CHUNK positions, then the partial rows of each token; ops.EMB_BWD_CHUNK) against fp32 index_add and against the
+    one-work-group-per-token form; run to run identical."""
+    ops = _ops()
+    g = torch.Generator(device=DEV).manual_seed(3)
+    T, V, D = 8192, 1000, 256
+    ids = torch.randint(0, V, (T,), device=DEV, generator=g)
+    ids[torch.rand(T, device=DEV, generator=g) < 0.33] = 7          # ~2700 positions
+    ids[torch.rand(T, device=DEV, generator=g) < 0.05] = 11         # ~400
+    ids[:300] = 13                                                  # 300+: three chunks of 128, the last one partial
+    dy = (torch.randn(T, D, device=DEV, generator=g)).to(BF)
+    ref = torch.zeros(V, D, dtype=torch.float32, device=DEV).index_add_(0, ids, dy.float())
+    dt = ops.embedding_bwd(dy, ids, V)
+    assert rel_l2(dt, ref) < 4e-3
+    assert torch.equal(dt, ops.embedding_bwd(dy, ids, V))
+    prev = ops.EMB_BWD_CHUNK
+    try:
+        ops.EMB_BWD_CHUNK = 0
+        dt0 = ops.embedding_bwd(dy, ids, V)
+    finally:
+        ops.EMB_BWD_CHUNK = prev
+    assert rel_l2(dt0, ref) < 4e-3
+    short = torch.bincount(ids, minlength=V) <= ops.EMB_BWD_CHUNK                  # single-chunk tokens: the same additions in the same order
+    assert torch.equal(dt[short], dt0[short])
+    assert rel_l2(dt, dt0.float()) < 4e-3
+
+
 def test_cross_entropy():
     ops = _ops()
     torch.manual_seed(4)
