@@ -91,6 +91,27 @@ __device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, 
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// SwiGLU forward product silu(gate) * up with the product kept apart from silu's division (same reason as swiglu_bwd_elem below)
+__device__ __forceinline__ float swiglu_fwd_elem(float x, float y) {
+#pragma clang fp reassociate(off) contract(off)
+    const float a = silu_f(x);
+    return a * y;
+}
+// SwiGLU backward of one element in ONE fixed operation order: d(gate) = (d y) * [sg (1 + x (1 - sg))], d(up) = d * (x sg), sg = sigmoid(x).
+// Shared by glu_bwd_kernel<0> and the SwiGLU-backward epilogue of the GEMM kernels (gemm_epilogues.h): left to -ffast-math the three call sites
+// (the element-wise kernel, the 8-wave GEMM, the four-wave GEMM) re-associated the triple product / contracted the inner sum differently and a
+// training step's gradients moved by an ulp with the kernel family (found by test_training_step_has_the_same_bits_on_either_gemm_kernel_family).
+__device__ __forceinline__ void swiglu_bwd_elem(float d, float x, float y, float& dgate, float& dup) {
+#pragma clang fp reassociate(off) contract(off)
+    const float sg = sigmoid_f(x);
+    const float act = x * sg;
+    const float om = 1.f - sg;
+    const float t = __builtin_fmaf(x, om, 1.f);
+    const float dact = sg * t;
+    const float dyv = d * y;
+    dgate = dyv * dact;
+    dup = d * act;
+}
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));

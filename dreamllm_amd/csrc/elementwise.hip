@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void glu_fwd_kernel(const bf16* __restrict__ a
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float x = (float)av[e], y = (float)bv[e];
-            o[e] = (bf16)((MODE == 0 ? silu_f(x) : gelu_erf_f(x)) * y);
+            o[e] = (bf16)(MODE == 0 ? swiglu_fwd_elem(x, y) : gelu_erf_f(x) * y);
         }
         stv<NT>(out + r * ldo + c, o);
     }
@@ -88,20 +88,21 @@ __global__ __launch_bounds__(256) void glu_bwd_kernel(const bf16* __restrict__ d
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float d = (float)dv[e], x = (float)av[e], y = (float)bv[e];
-            float act, dact;
-            if (MODE == 0) {
-                const float sg = sigmoid_f(x);
-                act = x * sg;
-                dact = sg * (1.f + x * (1.f - sg));
+            float act = 0.f;
+            if constexpr (MODE == 0) {   // fixed operation order shared with the GEMM epilogues (common.h)
+                float dg, du;
+                swiglu_bwd_elem(d, x, y, dg, du);
+                oa[e] = (bf16)dg;
+                ob[e] = (bf16)du;
             } else {
                 act = gelu_erf_f(x);
-                dact = gelu_erf_grad_f(x);
+                const float dact = gelu_erf_grad_f(x);
+                oa[e] = (bf16)(d * y * dact);
+                ob[e] = (bf16)(d * act);
             }
-            oa[e] = (bf16)(d * y * dact);
-            ob[e] = (bf16)(d * act);
             // the forward product, recomputed in the same pass for the down-projection's weight gradient: bit-identical to
             // glu_fwd_kernel (same silu_f / gelu_erf_f expression, one rounding)
-            oc[e] = (bf16)((MODE == 0 ? silu_f(x) : act) * y);
+            oc[e] = (bf16)(MODE == 0 ? swiglu_fwd_elem(x, y) : act * y);
         }
         stv<NT>(da + r * ldda + c, oa);
         stv<NT>(db + r * lddb + c, ob);

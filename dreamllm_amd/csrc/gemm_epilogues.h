@@ -54,7 +54,7 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_fwd(const GemmParams& P, f3
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x = (float)(bf16)(acc[i][j][e] * P.alpha), y = (float)(bf16)(acc[i][j + 2][e] * P.alpha);
-                    o[e] = (bf16)(silu_f(x) * y);
+                    o[e] = (bf16)swiglu_fwd_elem(x, y);
                 }
                 *reinterpret_cast<bf16x4*>(wl + 8192 + r * 128 + (((j * 4 + (lane >> 4)) ^ sw) << 3)) = o;
             }
@@ -140,11 +140,10 @@ __device__ __forceinline__ void gemm_epilogue_swiglu_bwd(const GemmParams& P, f3
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {   // glu_bwd_kernel<0>, on d_act rounded to bf16 as the unfused path stores it
                     const float d = (float)(bf16)(acc[i][j][e] * P.alpha), x = (float)gv[e], y = (float)uv[e];
-                    const float sg = sigmoid_f(x);
-                    const float act = x * sg;
-                    const float dact = sg * (1.f + x * (1.f - sg));
-                    oa[e] = (bf16)(d * y * dact);
-                    ob[e] = (bf16)(d * act);
+                    float dg, du;
+                    swiglu_bwd_elem(d, x, y, dg, du);
+                    oa[e] = (bf16)dg;
+                    ob[e] = (bf16)du;
                 }
                 *reinterpret_cast<bf16x4*>(w0 + off) = oa;
                 *reinterpret_cast<bf16x4*>(w1 + off) = ob;

@@ -1240,6 +1240,43 @@ def test_gemm_w4m_equals_the_8_wave_kernel(layout, ragged):
         assert torch.equal(y, y0)
 
 
+def test_fused_gemm_epilogues_have_the_same_bits_on_both_kernel_families():
+    """The three fused launches of the decoder layer (gate|up + SwiGLU, down-projection dgrad + SwiGLU backward, q|k|v + RoPE) on the four-wave
+    kernel (gemm_variant 280 -> bits 8-9 of group_m) against the 8-wave kernel (259), more than one round of tiles: identical outputs.  The
+    SwiGLU arithmetic is one fixed operation order (common.h: swiglu_fwd_elem / swiglu_bwd_elem) -- left to -ffast-math the call sites differed
+    by an ulp."""
+    ops = _ops()
+    from oracle import llm_ref
+    g = torch.Generator(device=DEV).manual_seed(21)
+    rn = lambda *s, scale=1.0: (torch.randn(*s, device=DEV, generator=g) * scale).to(BF)
+    M, K, F_, D = 4352, 512, 2048, 128
+    x, wgu = rn(M, K), rn(2 * F_, K, scale=K ** -0.5)
+    dy, wd, gu = rn(M, K), rn(K, F_, scale=K ** -0.5), rn(M, 2 * F_)
+    Hq = Hkv = 8
+    wqkv = rn((Hq + 2 * Hkv) * D, K, scale=K ** -0.5)
+    cos, sin = llm_ref.rope_tables(D, 1024)
+    ct, st = cos[:, : D // 2].contiguous().to(DEV), sin[:, : D // 2].contiguous().to(DEV)
+    pos = torch.randint(0, 1024, (M,), device=DEV, generator=g)
+    outs = {}
+    for code in (259, 280):
+        with ops.gemm_variant(code):
+            a = ops.linear_swiglu_fwd(x, wgu)
+            b = ops.linear_dgrad_swiglu(dy, wd, gu)
+            c = ops.linear_rope_qkv(x, wqkv, ct, st, pos, Hq + Hkv, D, 256)
+        assert a is not None and b is not None and c is not None
+        outs[code] = (a[0], a[1], b, c)
+    for t259, t280 in zip(outs[259], outs[280]):
+        assert torch.equal(t259, t280)
+    # and against the unfused pair on the element-wise kernels
+    with ops.gemm_variant(259):
+        gu0 = ops.linear_fwd(x, wgu)
+        dact = ops.linear_dgrad(dy, wd)
+    assert torch.equal(outs[280][0], gu0)
+    assert torch.equal(outs[280][1], ops.glu_fwd(gu0[:, :F_], gu0[:, F_:], 0))
+    dg, du = ops.glu_bwd(dact, gu[:, :F_], gu[:, F_:], 0)
+    assert torch.equal(outs[280][2][:, :F_], dg) and torch.equal(outs[280][2][:, F_:], du)
+
+
 @pytest.mark.parametrize("M,Hq,Hkv,K,with_pos", [(256, 2, 2, 64, False), (512, 4, 2, 256, True), (1024, 6, 2, 320, False), (2048, 32, 32, 4096, True)])
 def test_gemm_rope_qkv_equals_gemm_plus_rope(M, Hq, Hkv, K, with_pos):
     """packed q|k|v projection with the rotary embedding in its epilogue (dllm_gemm_rope_qkv, head_dim 128) == GEMM + dllm_rope on the q and

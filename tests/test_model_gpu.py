@@ -549,6 +549,37 @@ def test_training_step_is_bit_reproducible():
             assert torch.equal(g[n], g0[n]), (rep, n)
 
 
+def test_training_step_has_the_same_bits_on_either_gemm_kernel_family():
+    """Round 6: the four-wave GEMM kernel (csrc/gemm_w4.hip) takes the decoder's linears from 256 full tiles on; it adds the products in the order
+    of the 8-wave kernel, so a training step must not change by one bit.  A 2-layer model wide enough for the library to pick it (hidden 1024,
+    MLP 4096, 8192 tokens: 128 ... 512 tiles per launch -- the packed q|k|v, gate|up + SwiGLU, down-dgrad + SwiGLU-backward and weight-gradient
+    launches of >= 256 tiles run on it), stepped with DREAMLLM_W4M on and off: loss and every gradient bit-identical."""
+    from dreamllm_amd import ops
+    from dreamllm_amd.factory import TINY_CLIP, TINY_DIFFUSION, build_dreamllm
+    from dreamllm_amd.synthetic import make_interleaved_batch
+    cfg = dict(hidden_size=1024, intermediate_size=4096, num_hidden_layers=2, num_attention_heads=8, max_position_embeddings=2048, rms_norm_eps=1e-6)
+    m = build_dreamllm(cfg, device=DEV, seed=0, clip=TINY_CLIP, diffusion=TINY_DIFFUSION, num_dream_queries=8).train()
+    batch = make_interleaved_batch(4, 2048, 1, n_dream=8, n_patch=16, seed=11, device=DEV, image_size=56, dm_size=128)
+
+    def run(w4m):
+        prev, ops.W4M = ops.W4M, w4m
+        try:
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            out = m(**batch, return_dict=True)
+            out.loss.backward()
+            return out.loss.detach().clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            ops.W4M = prev
+
+    l1, g1 = run(True)
+    l0, g0 = run(False)
+    assert torch.equal(l1, l0)
+    assert g1.keys() == g0.keys() and len(g1) > 10
+    for n in g1:
+        assert torch.equal(g1[n], g0[n]), n
+
+
 def test_ragged_batch_on_compact_rows_matches_the_padded_grid():
     """Round 6: a right-padded ragged training batch with `seqlens` runs the decoder on COMPACT rows (valid tokens back to back, attention
     alone on the padded grid).  Loss, both loss terms and every gradient must agree with the padded-grid path (same kernels on the same
