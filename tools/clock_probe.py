@@ -1,4 +1,4 @@
-"""Sustained clocks / power while one kernel family runs back to back: python tools/clock_probe.py {attn_bwd,attn_fwd,gemm,gemm259,gemm261,idle}
+"""Sustained clocks / power while one kernel family runs back to back: python tools/clock_probe.py {attn_bwd,attn_fwd,gemm,gemm259,gemm280,gemm261,idle}
 Polls rocm-smi once per second from a thread while the main thread keeps the GPU busy for ~6 s."""
 import os
 import subprocess
@@ -43,7 +43,7 @@ while time.time() - t0 < 6.0:
             ops.attn_fwd(q, k, v, True)
         elif what == "gemm":
             ops.linear_fwd(a, w)
-        elif what.startswith("gemm"):     # gemm259 / gemm261: one kernel family (tile code) on the packed gate|up forward shape
+        elif what.startswith("gemm"):     # gemm259 / gemm280 / gemm261: one kernel family (tile code) on the packed gate|up forward shape
             with ops.gemm_variant(int(what[4:])):
                 ops.linear_fwd(a, w2)
         else:
