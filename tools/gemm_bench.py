@@ -1,5 +1,6 @@
 """GEMM kernel variants on the shapes of the headline step, interleaved in one process (box-to-box variance is larger than the
-differences): python tools/gemm_bench.py [variants, default 259,261].  259 = 8-wave pipelined kernel, 261 = 4-wave kernel."""
+differences): python tools/gemm_bench.py [variants, default 259,280].  259 = 8-wave pipelined kernel, 280 = four-wave kernel (261: its MFMA 32x32x16
+experiment).  SHORT bursts: the clock has not settled on the power limit and the ranking differs from sustained runs -- use gemm_ab_sustained.py to decide."""
 import os
 import sys
 
@@ -9,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dreamllm_amd import ops  # noqa: E402
 
 BF = torch.bfloat16
-variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "259,261").split(",")]
+variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "259,280").split(",")]
 
 
 def timed(fn, iters=10):
