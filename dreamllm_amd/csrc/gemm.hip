@@ -1092,7 +1092,10 @@ static inline bool streamk_plan_small(int64_t M, int64_t N, int64_t K, int& tail
     const int64_t nt = K / BK;
     // N >= 512: at N = 320 (the UNet's first level) the 256-wide tiles waste 37 % of their columns and the fix-up launch alone costs
     // 60 us; the ring kernel runs [8192, 320, 8640] in 97 us against 140 us for this path (profiles/r04_denoise_kernel_stats.csv)
-    if (tiles < 48 || tiles > 208 || nt < 96 || (K % BK) != 0 || N < 512) return false;
+    // (round 6: at most HALF a round of tiles instead of 208 -- at 192 tiles (the UNet's 640-channel convs at 32 x 32, batch 16) the plain whole-tile
+    // launch measured 18-19 % faster at K = 8640 / 17280 and equal at 11520; at 160 tiles (the 1280-channel convs at 16 x 16, batch 32) 15 % / 10 %
+    // faster at K = 11520 / 17280 and 12 % slower at 23040: profiles/r06_unet_conv_family_ab.log)
+    if (tiles < 48 || tiles > 128 || nt < 96 || (K % BK) != 0 || N < 512) return false;
     const int64_t total = tiles * nt;
     w = (int)cdiv64(total, 256);
     if (w < 32) return false;

@@ -109,8 +109,9 @@ def test_scheduling_hints_are_pure_host_functions():
     for shape in [(d, F_, T, 1, 1), (3 * d, d, T, 1, 1), (d, d, T, 1, 1), (T, F_, d, 0, 1), (T, 2 * F_, d, 0, 0), (T, d, d, 0, 0),
                   (T, d, F_, 0, 0), (T, 3 * d, d, 0, 0), (T, d, 2 * F_, 0, 1)]:
         assert sk(*shape) == 0, shape
-    # small grid, deep K (layout 2 = implicit-GEMM conv): the UNet's 1280-channel 3x3 convs at 16 x 16, batch 16 and 32
-    assert sk(16 * 256, 1280, 9 * 1280, 2, 0) == 1 and sk(32 * 256, 1280, 9 * 2560, 2, 0) == 1
+    # small grid, deep K (layout 2 = implicit-GEMM conv): the UNet's 1280-channel 3x3 convs at 16 x 16, batch 16 (80 tiles); at batch 32 (160
+    # tiles: more than half a round) and for the 640-channel convs at 32 x 32, batch 16 (192 tiles) the whole-tile launch is faster (round 6)
+    assert sk(16 * 256, 1280, 9 * 1280, 2, 0) == 1 and sk(32 * 256, 1280, 9 * 2560, 2, 0) == 0 and sk(16 * 1024, 640, 9 * 1920, 2, 0) == 0
     assert sk(2 * 256, 1280, 9 * 1280, 2, 0) == 0           # batch 2: 10 tiles -> the split-K kernels
     assert sk(16 * 4096, 320, 9 * 320, 2, 0) == 0           # 512 tiles: whole rounds
     # split-K of tiny grids (the denoise loop at batch 2)
