@@ -102,8 +102,8 @@ def run_conv(N, H, C, CO, k, stride, up, variant, sk):
     return graph_time(fn)
 
 
-def sk_candidates(M, N, K):
-    hint = _lib.call("dllm_gemm_splitk_hint", M, N, K)
+def sk_candidates(M, N, K, la=0):
+    hint = _lib.call("dllm_gemm_splitk_hint", M, N, K, la, 0)   # (round 6: the hint takes the layouts; la = 2: the NHWC conv gather)
     tiles = -(-M // 128) * -(-N // 128)
     kt = K // 64
     cands = {1, hint}
@@ -147,7 +147,7 @@ def main():
     for cnt, H, C, CO, k, stride, up in CONVS:
         OH = H * (2 if up else 1) // stride
         M, K = NB * OH * OH, k * k * C
-        hint, cands = sk_candidates(M, CO, K)
+        hint, cands = sk_candidates(M, CO, K, 2)
         res = {}
         res["auto"] = run_conv(NB, H, C, CO, k, stride, up, 0, hint)
         res["old128"] = run_conv(NB, H, C, CO, k, stride, up, 128, hint)
