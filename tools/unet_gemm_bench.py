@@ -124,6 +124,7 @@ def main():
     for cnt, M, N, K, tag in ([] if CONVS_ONLY else LINEARS):
         hint, cands = sk_candidates(M, N, K)
         res = {}
+        run_linear(M, N, K, 0, hint)               # (untimed: the first measurement of a shape runs on clocks that are still ramping)
         res["auto"] = run_linear(M, N, K, 0, hint)
         res["old128"] = run_linear(M, N, K, 128, hint)
         for sk in cands:
@@ -149,6 +150,7 @@ def main():
         M, K = NB * OH * OH, k * k * C
         hint, cands = sk_candidates(M, CO, K, 2)
         res = {}
+        run_conv(NB, H, C, CO, k, stride, up, 0, hint)
         res["auto"] = run_conv(NB, H, C, CO, k, stride, up, 0, hint)
         res["old128"] = run_conv(NB, H, C, CO, k, stride, up, 128, hint)
         for sk in cands:
