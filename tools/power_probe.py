@@ -4,7 +4,7 @@ Runs the packed gate|up forward shape [32768 x 22016 x 4096] back to back for ~5
   blaslt    torch.matmul (hipBLASLt's pick for the shape) -- a yard-stick for tools only, never part of the product
 on three kinds of operand data: N(0,1) bf16 (what bench.py uses), small integers {-1,0,1} (few mantissa bits toggle), zeros.
 Prints ms per launch (HIP events around 20 launches, median), TFLOP/s, sclk and socket power per sample.
-  python tools/power_probe.py [seconds] [tile codes] [kinds, default normal,ints,zeros] [noblaslt]     tile codes of ours, default 259; e.g. 259,261 adds the four-wave experiment kernel]"""
+  python tools/power_probe.py [seconds] [tile codes] [kinds, default normal,ints,zeros] [noblaslt|blaslt] [fwd|dgrad|wgrad]     tile codes of ours, default 259; e.g. 259,261 adds the four-wave experiment kernel]"""
 import os
 import subprocess
 import sys
@@ -20,6 +20,7 @@ SECS = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
 CODES = [int(c) for c in (sys.argv[2] if len(sys.argv) > 2 else "259").split(",")]
 KINDS = (sys.argv[3] if len(sys.argv) > 3 else "normal,ints,zeros").split(",")
 BLASLT = not (len(sys.argv) > 4 and sys.argv[4] == "noblaslt")
+LAYOUT = sys.argv[5] if len(sys.argv) > 5 else "fwd"   # fwd: y = x W^T; dgrad: dx = dy W; wgrad: dW = dy^T x (the same three matrices)
 M, N, K = 32768, 22016, 4096
 BF = torch.bfloat16
 FLOP = 2.0 * M * N * K
@@ -80,10 +81,17 @@ def run(tag, fn):
 for kind in KINDS:
     a, w = data(kind)
     wt = w.t()
+    if LAYOUT != "fwd":
+        g = torch.Generator(device="cuda").manual_seed(1)
+        dy = (torch.zeros(M, N, device="cuda", dtype=BF) if kind == "zeros" else
+              torch.randint(-1, 2, (M, N), device="cuda", generator=g).to(BF) if kind == "ints" else torch.randn(M, N, device="cuda", generator=g).to(BF))
+        dyt = dy.t()
+    ours = {"fwd": lambda: ops.linear_fwd(a, w), "dgrad": lambda: ops.linear_dgrad(dy, w), "wgrad": lambda: ops.linear_wgrad(dy, a)}[LAYOUT]
+    theirs = {"fwd": lambda: torch.matmul(a, wt), "dgrad": lambda: torch.matmul(dy, w), "wgrad": lambda: torch.matmul(dyt, a)}[LAYOUT]
     for code in CODES:
         with ops.gemm_variant(code):
-            run(f"ours {code} {kind}", lambda: ops.linear_fwd(a, w))
+            run(f"ours {code} {LAYOUT} {kind}", ours)
     if BLASLT:
-        run(f"blaslt {kind}", lambda: torch.matmul(a, wt))
+        run(f"blaslt {LAYOUT} {kind}", theirs)
     time.sleep(2.0)
     del a, w, wt
